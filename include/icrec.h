@@ -1,0 +1,197 @@
+/*
+ * icrec.h — C ABI of libicrec.so, the MI355X (gfx950) implementation of the
+ * reference's SBERT-encode -> cosine-similarity -> top-k hot path.
+ *
+ * The reference (chen-bowen/instacart_next_order_recommendation) has no FFI of
+ * its own: its seam is the Python duck type `Recommender.recommend()`
+ * (src/inference/serve_recommendations.py:206-225).  Each entry point below
+ * names the reference call it replaces.  The Python host classes in
+ * instacart_next_order_recommendation_amd/ bind these symbols with ctypes
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative ICREC_E* code on failure;
+ *    icrec_last_error() returns a thread-local message for the last failure.
+ *  - handles are opaque, owned by the library until the matching *_destroy.
+ *  - "dev" pointers are device (HBM) pointers, borrowed for the duration of
+ *    the call's stream work; "host" pointers are read before the call returns.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *    work is enqueued asynchronously; nothing here synchronises the device
+ *    except *_create/_destroy.
+ *  - scratch memory is supplied by the caller (`workspace`), sized by the
+ *    matching *_workspace_bytes(); the library never allocates on the hot path
+ *    so every call is hipGraph-capturable.
+ *  - no torch / C++ types cross this boundary.
+ */
+#ifndef ICREC_H
+#define ICREC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICREC_VERSION_MAJOR 0
+#define ICREC_VERSION_MINOR 1
+
+enum {
+    ICREC_OK = 0,
+    ICREC_EINVAL = -1,   /* bad argument (shape, NULL, k out of range ...) */
+    ICREC_EHIP = -2,     /* a HIP runtime call failed                      */
+    ICREC_ENOMEM = -3,   /* workspace too small / allocation failed        */
+    ICREC_ENODEV = -4    /* no gfx950 device visible                        */
+};
+
+/* k is bounded by the reference's API schema (src/api/schemas.py:34, top_k<=100);
+ * the kernels are built for k <= ICREC_MAX_K. */
+#define ICREC_MAX_K 128
+
+typedef struct icrec_encoder icrec_encoder;
+typedef struct icrec_index icrec_index;
+
+/* ------------------------------------------------------------------------- */
+/* Encoder: replaces SentenceTransformer.encode's device work                 */
+/* (serve_recommendations.py:195-200, :213, :246): BertModel forward          */
+/* (transformers modeling_bert.py BertEmbeddings/BertLayer), mean pooling,    */
+/* L2 normalisation.  Tokenisation stays on the host.                         */
+/* ------------------------------------------------------------------------- */
+
+typedef struct icrec_bert_cfg {
+    int32_t vocab_size;    /* 30522 for all-MiniLM-L6-v2                     */
+    int32_t hidden;        /* 384  (must be 384 in this build)               */
+    int32_t layers;        /* 6                                              */
+    int32_t heads;         /* 12   (head_dim must be 32 in this build)       */
+    int32_t intermediate;  /* 1536 (must be a multiple of 128)               */
+    int32_t max_position;  /* 512                                            */
+    int32_t type_vocab;    /* 2                                              */
+    float   ln_eps;        /* 1e-12                                          */
+    int32_t n_normalize;   /* how many times x / max(|x|_2, 1e-12) is applied
+                              after pooling: 1 for the ST `Normalize` module,
+                              +1 for encode(normalize_embeddings=True)       */
+} icrec_bert_cfg;
+
+/* Number of fp32 elements the weight blob must hold for `cfg`.
+ * Blob layout (all fp32, row-major, HF `nn.Linear` weights are [out,in]):
+ *   word_emb[V,H] pos_emb[P,H] type_emb[Tv,H] emb_ln_g[H] emb_ln_b[H]
+ *   then per layer:
+ *   Wq[H,H] bq[H] Wk[H,H] bk[H] Wv[H,H] bv[H] Wo[H,H] bo[H] ln1_g[H] ln1_b[H]
+ *   W1[I,H] b1[I] W2[H,I] b2[H] ln2_g[H] ln2_b[H]
+ * (the BertPooler is not used by mean pooling and is not part of the blob). */
+size_t icrec_encoder_weight_count(const icrec_bert_cfg* cfg);
+
+/* Upload weights (host pointer; the library copies them to `device`). */
+int icrec_encoder_create(const float* weights_host, size_t n_floats,
+                         const icrec_bert_cfg* cfg, int device,
+                         icrec_encoder** out);
+int icrec_encoder_destroy(icrec_encoder* enc);
+
+/* Scratch bytes needed to encode `total_tokens` tokens in `n_seqs` sequences. */
+size_t icrec_encode_workspace_bytes(const icrec_encoder* enc,
+                                    int64_t total_tokens, int32_t n_seqs);
+
+/* Encode a token-packed batch.
+ *   ids_dev        int32[total_tokens]  WordPiece ids, sequences back to back
+ *                                       (already truncated to max_seq_length,
+ *                                       [CLS]/[SEP] included; no pad tokens)
+ *   cu_seqlens_dev int32[n_seqs+1]      prefix sums of sequence lengths
+ *   max_seqlen     longest sequence in the batch (<= 256 in this build)
+ *   out_dev        float[n_seqs, hidden] L2-normalised sentence embeddings
+ * Padding never enters the math: the reference pads per batch and masks the
+ * pad keys to weight exactly 0, so the packed form is the same function.     */
+int icrec_encode(icrec_encoder* enc,
+                 const int32_t* ids_dev, const int32_t* cu_seqlens_dev,
+                 int32_t n_seqs, int64_t total_tokens, int32_t max_seqlen,
+                 float* out_dev,
+                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Index + search: replaces cos_sim(query_emb, product_embeddings)            */
+/* (serve_recommendations.py:214/:250), scores.argsort(descending=True)       */
+/* (:215/:251) and the exclusion/top-k loop (:216-225/:254-262).              */
+/* ------------------------------------------------------------------------- */
+
+/* Build an index over a [n_rows, dim] fp32 row-major matrix in device memory.
+ * The library keeps its own copy with every row divided by max(|row|_2,1e-12)
+ * (what cos_sim does to its second operand on every call in the reference).
+ * `row_offset` is added to every returned row index (catalog shards).        */
+int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim,
+                       int64_t row_offset, int device, icrec_index** out);
+int icrec_index_destroy(icrec_index* idx);
+int64_t icrec_index_rows(const icrec_index* idx);
+
+/* Copy the normalised rows back out (row-major fp32 [n_rows, dim]); used by the
+ * parity tests and by EmbeddingIndex.save.                                   */
+int icrec_index_export(const icrec_index* idx, float* rows_dev, void* stream);
+
+size_t icrec_search_workspace_bytes(const icrec_index* idx, int32_t n_queries,
+                                    int32_t k);
+
+/* Top-k search.
+ *   q_dev        float[n_queries, dim]  query embeddings (any norm; normalised
+ *                                       here exactly as cos_sim does)
+ *   excl_idx_dev int32[excl_off[n_queries]] LOCAL row numbers to skip, sorted
+ *                ascending and unique within each query's segment (or NULL)
+ *   excl_off_dev int32[n_queries+1]     CSR offsets into excl_idx_dev (or NULL)
+ *   out_idx_dev  int64[n_queries, k]    row_offset + row, best first; -1 pads
+ *                                       when fewer than k rows remain
+ *   out_score_dev float[n_queries, k]   cosine scores (0 where idx == -1)
+ * Order: score descending, ties by lower row index first.
+ * Every score is the fp32 chain s = fmaf(q[j], p[j], s) for j = 0..dim-1,
+ * bit-identical to oracle/icrec_oracle.c:icrec_oracle_scores.                */
+int icrec_search(icrec_index* idx, const float* q_dev, int32_t n_queries,
+                 int32_t k,
+                 const int32_t* excl_idx_dev, const int32_t* excl_off_dev,
+                 int64_t* out_idx_dev, float* out_score_dev,
+                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Shard-local half of a sharded search: same as icrec_search but emits the
+ * sorted partial lists as packed 64-bit keys
+ *   key = (orderable(score) << 32) | (0xFFFFFFFF - global_row)
+ * so that a larger key is a better hit under (score desc, row asc).
+ *   out_keys_dev uint64[n_queries, k], best first; 0 pads.                   */
+int icrec_search_partial(icrec_index* idx, const float* q_dev,
+                         int32_t n_queries, int32_t k,
+                         const int32_t* excl_idx_dev,
+                         const int32_t* excl_off_dev,
+                         uint64_t* out_keys_dev,
+                         void* workspace_dev, size_t workspace_bytes,
+                         void* stream);
+
+/* Merge `n_lists` sorted partial lists per query (e.g. the all-gathered
+ * per-shard lists, laid out [n_lists, n_queries, k] as an all-gather leaves
+ * them) into the final top-k.  Needs no index handle.                        */
+int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists,
+                     int32_t n_queries, int32_t k,
+                     int64_t* out_idx_dev, float* out_score_dev,
+                     int device, void* stream);
+
+/* Full score row(s) for parity checks: out[n_queries, n_rows] = q_hat . p_hat.
+ * Not on the serving path (the serving kernels never materialise scores).    */
+int icrec_scores(icrec_index* idx, const float* q_dev, int32_t n_queries,
+                 float* out_dev, void* workspace_dev, size_t workspace_bytes,
+                 void* stream);
+
+/* L2-normalise rows in place-compatible fashion: out = x / max(|x|_2, eps).
+ * (torch.nn.functional.normalize(p=2, dim=1) as used by cos_sim.)            */
+int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n_rows,
+                         int32_t dim, float eps, int device, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Diagnostics                                                                */
+/* ------------------------------------------------------------------------- */
+const char* icrec_last_error(void);
+const char* icrec_version(void);
+/* Average duration (ms) of the dominant kernel over the launches recorded
+ * since the last reset, measured with hipEvents on the launch stream.
+ * which: 0 = search score+select kernel, 1 = encoder FFN-up GEMM,
+ *        2 = whole encode() call, 3 = whole search() call.                   */
+int icrec_timing_enable(int on);
+int icrec_timing_reset(void);
+int icrec_timing_query(int which, double* avg_ms, int64_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICREC_H */
