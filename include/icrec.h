@@ -33,6 +33,9 @@
 extern "C" {
 #endif
 
+/* every entry point is exported from libicrec.so (built with -fvisibility=hidden) */
+#define ICREC_API __attribute__((visibility("default")))
+
 #define ICREC_VERSION_MAJOR 0
 #define ICREC_VERSION_MINOR 1
 
@@ -79,16 +82,16 @@ typedef struct icrec_bert_cfg {
  *   Wq[H,H] bq[H] Wk[H,H] bk[H] Wv[H,H] bv[H] Wo[H,H] bo[H] ln1_g[H] ln1_b[H]
  *   W1[I,H] b1[I] W2[H,I] b2[H] ln2_g[H] ln2_b[H]
  * (the BertPooler is not used by mean pooling and is not part of the blob). */
-size_t icrec_encoder_weight_count(const icrec_bert_cfg* cfg);
+ICREC_API size_t icrec_encoder_weight_count(const icrec_bert_cfg* cfg);
 
 /* Upload weights (host pointer; the library copies them to `device`). */
-int icrec_encoder_create(const float* weights_host, size_t n_floats,
+ICREC_API int icrec_encoder_create(const float* weights_host, size_t n_floats,
                          const icrec_bert_cfg* cfg, int device,
                          icrec_encoder** out);
-int icrec_encoder_destroy(icrec_encoder* enc);
+ICREC_API int icrec_encoder_destroy(icrec_encoder* enc);
 
 /* Scratch bytes needed to encode `total_tokens` tokens in `n_seqs` sequences. */
-size_t icrec_encode_workspace_bytes(const icrec_encoder* enc,
+ICREC_API size_t icrec_encode_workspace_bytes(const icrec_encoder* enc,
                                     int64_t total_tokens, int32_t n_seqs);
 
 /* Encode a token-packed batch.
@@ -100,7 +103,7 @@ size_t icrec_encode_workspace_bytes(const icrec_encoder* enc,
  *   out_dev        float[n_seqs, hidden] L2-normalised sentence embeddings
  * Padding never enters the math: the reference pads per batch and masks the
  * pad keys to weight exactly 0, so the packed form is the same function.     */
-int icrec_encode(icrec_encoder* enc,
+ICREC_API int icrec_encode(icrec_encoder* enc,
                  const int32_t* ids_dev, const int32_t* cu_seqlens_dev,
                  int32_t n_seqs, int64_t total_tokens, int32_t max_seqlen,
                  float* out_dev,
@@ -116,16 +119,16 @@ int icrec_encode(icrec_encoder* enc,
  * The library keeps its own copy with every row divided by max(|row|_2,1e-12)
  * (what cos_sim does to its second operand on every call in the reference).
  * `row_offset` is added to every returned row index (catalog shards).        */
-int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim,
+ICREC_API int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim,
                        int64_t row_offset, int device, icrec_index** out);
-int icrec_index_destroy(icrec_index* idx);
-int64_t icrec_index_rows(const icrec_index* idx);
+ICREC_API int icrec_index_destroy(icrec_index* idx);
+ICREC_API int64_t icrec_index_rows(const icrec_index* idx);
 
 /* Copy the normalised rows back out (row-major fp32 [n_rows, dim]); used by the
  * parity tests and by EmbeddingIndex.save.                                   */
-int icrec_index_export(const icrec_index* idx, float* rows_dev, void* stream);
+ICREC_API int icrec_index_export(const icrec_index* idx, float* rows_dev, void* stream);
 
-size_t icrec_search_workspace_bytes(const icrec_index* idx, int32_t n_queries,
+ICREC_API size_t icrec_search_workspace_bytes(const icrec_index* idx, int32_t n_queries,
                                     int32_t k);
 
 /* Top-k search.
@@ -140,7 +143,7 @@ size_t icrec_search_workspace_bytes(const icrec_index* idx, int32_t n_queries,
  * Order: score descending, ties by lower row index first.
  * Every score is the fp32 chain s = fmaf(q[j], p[j], s) for j = 0..dim-1,
  * bit-identical to oracle/icrec_oracle.c:icrec_oracle_scores.                */
-int icrec_search(icrec_index* idx, const float* q_dev, int32_t n_queries,
+ICREC_API int icrec_search(icrec_index* idx, const float* q_dev, int32_t n_queries,
                  int32_t k,
                  const int32_t* excl_idx_dev, const int32_t* excl_off_dev,
                  int64_t* out_idx_dev, float* out_score_dev,
@@ -151,7 +154,7 @@ int icrec_search(icrec_index* idx, const float* q_dev, int32_t n_queries,
  *   key = (orderable(score) << 32) | (0xFFFFFFFF - global_row)
  * so that a larger key is a better hit under (score desc, row asc).
  *   out_keys_dev uint64[n_queries, k], best first; 0 pads.                   */
-int icrec_search_partial(icrec_index* idx, const float* q_dev,
+ICREC_API int icrec_search_partial(icrec_index* idx, const float* q_dev,
                          int32_t n_queries, int32_t k,
                          const int32_t* excl_idx_dev,
                          const int32_t* excl_off_dev,
@@ -162,34 +165,34 @@ int icrec_search_partial(icrec_index* idx, const float* q_dev,
 /* Merge `n_lists` sorted partial lists per query (e.g. the all-gathered
  * per-shard lists, laid out [n_lists, n_queries, k] as an all-gather leaves
  * them) into the final top-k.  Needs no index handle.                        */
-int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists,
+ICREC_API int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists,
                      int32_t n_queries, int32_t k,
                      int64_t* out_idx_dev, float* out_score_dev,
                      int device, void* stream);
 
 /* Full score row(s) for parity checks: out[n_queries, n_rows] = q_hat . p_hat.
  * Not on the serving path (the serving kernels never materialise scores).    */
-int icrec_scores(icrec_index* idx, const float* q_dev, int32_t n_queries,
+ICREC_API int icrec_scores(icrec_index* idx, const float* q_dev, int32_t n_queries,
                  float* out_dev, void* workspace_dev, size_t workspace_bytes,
                  void* stream);
 
 /* L2-normalise rows in place-compatible fashion: out = x / max(|x|_2, eps).
  * (torch.nn.functional.normalize(p=2, dim=1) as used by cos_sim.)            */
-int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n_rows,
+ICREC_API int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n_rows,
                          int32_t dim, float eps, int device, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Diagnostics                                                                */
 /* ------------------------------------------------------------------------- */
-const char* icrec_last_error(void);
-const char* icrec_version(void);
+ICREC_API const char* icrec_last_error(void);
+ICREC_API const char* icrec_version(void);
 /* Average duration (ms) of the dominant kernel over the launches recorded
  * since the last reset, measured with hipEvents on the launch stream.
  * which: 0 = search score+select kernel, 1 = encoder FFN-up GEMM,
  *        2 = whole encode() call, 3 = whole search() call.                   */
-int icrec_timing_enable(int on);
-int icrec_timing_reset(void);
-int icrec_timing_query(int which, double* avg_ms, int64_t* n_launches);
+ICREC_API int icrec_timing_enable(int on);
+ICREC_API int icrec_timing_reset(void);
+ICREC_API int icrec_timing_query(int which, double* avg_ms, int64_t* n_launches);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,470 @@
+// search.hip — cosine scoring fused with per-query top-k selection (no score matrix is
+// ever written), the k-way merge of sorted partial lists, and row L2-normalisation.
+//
+// Replaces, on the device:
+//   sentence_transformers.util.cos_sim(query_emb, product_embeddings)  serve_recommendations.py:214/:250
+//   scores.argsort(descending=True)                                      :215/:251
+//   the exclusion / top-k Python loop                                    :216-225/:254-262
+// of /root/reference/src/inference/serve_recommendations.py.
+#include "common.h"
+
+namespace icrec {
+
+// ---------------------------------------------------------------- row normalisation
+// out = x / max(|x|_2, eps) — torch.nn.functional.normalize(p=2, dim=1) as cos_sim applies it.
+// One wavefront per row; reduction order = 64 strided fmaf partials + xor butterfly, identical
+// to oracle/icrec_oracle.c:wave_sum(mode 2).
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             int64_t n_rows, int64_t n_out_rows, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_out_rows) return;
+    if (row >= n_rows) {  // zero padding rows (query tiles are padded to the tile width)
+        for (int i = lane; i < dim; i += 64) out[row * dim + i] = 0.0f;
+        return;
+    }
+    const float* xr = x + row * dim;
+    float acc = 0.0f;
+    for (int i = lane; i < dim; i += 64) {
+        float v = xr[i];
+        acc = fmaf(v, v, acc);
+    }
+    float nrm = sqrtf(wave_sum_f32(acc));
+    float den = nrm > eps ? nrm : eps;
+    for (int i = lane; i < dim; i += 64) out[row * dim + i] = xr[i] / den;
+}
+
+// ---------------------------------------------------------------- score + select
+constexpr int QCAP = 16;  // candidate queue slots per query between two list merges
+
+template <class Cfg>
+struct SearchSmem {
+    // dynamic LDS carve (all offsets multiples of 16 B)
+    static __host__ __device__ size_t bytes(int k) {
+        return (size_t)Cfg::LDS_FLOATS * 4 + (size_t)Cfg::BN * (8 /*thr*/ + 4 /*cnt*/) + 16 /*flags*/ +
+               (size_t)Cfg::BN * k * 8 + (size_t)Cfg::BN * QCAP * 8;
+    }
+};
+
+// Is local row `row` in the sorted exclusion segment [lo, hi)?
+__device__ __forceinline__ bool excluded(const int32_t* __restrict__ ex, int lo, int hi, int row) {
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        int v = ex[mid];
+        if (v == row) return true;
+        if (v < row) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// Merge the queue of query q into its sorted list; one wavefront, all 64 lanes call this.
+__device__ __forceinline__ void merge_queue(u64* list, const u64* queue, int n, int k, int lane) {
+    u64 c = lane < n ? queue[lane] : 0ull;
+    u64 e0 = lane < k ? list[lane] : 0ull;
+    u64 e1 = lane + 64 < k ? list[lane + 64] : 0ull;
+    int rc = 0, r0 = 0, r1 = 0;
+    for (int i = 0; i < n; ++i) {
+        u64 ci = queue[i];  // LDS broadcast
+        rc += ci > c;
+        r0 += ci > e0;
+        r1 += ci > e1;
+    }
+    // number of list entries better than my candidate: binary search in the descending list
+    int lo = 0, hi = k;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (list[mid] > c) lo = mid + 1; else hi = mid;
+    }
+    const int pc = rc + lo, p0 = lane + r0, p1 = lane + 64 + r1;
+    // all reads above are complete (their values are consumed) before any lane writes
+    if (lane < n && pc < k) list[pc] = c;
+    if (lane < k && p0 < k) list[p0] = e0;
+    if (lane + 64 < k && p1 < k) list[p1] = e1;
+}
+
+// Grid: n_chunks * n_qtiles blocks (XCD-remapped).  Block (chunk, qtile) scores catalog row
+// tiles [chunk*tiles_per_chunk, ...) against query tile qtile and keeps, per query, the k best
+// (score, row) seen, then writes them (sorted, as keys) to partial[chunk][query][0..k).
+// EMIT = true additionally stores every score to scores_out[q*N + row] (parity checks only).
+template <class Cfg, bool EMIT>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
+    const float* __restrict__ P, int64_t N, int K, const float* __restrict__ Qn, int Qpad, int Q, int k,
+    const int32_t* __restrict__ excl_idx, const int32_t* __restrict__ excl_off, uint32_t row_base,
+    int n_row_tiles, int tiles_per_chunk, int n_qtiles, u64* __restrict__ partial, float* __restrict__ scores_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* As = reinterpret_cast<float*>(smem_raw);
+    float* Bs = As + Cfg::BM * LDK;
+    u64* thr = reinterpret_cast<u64*>(Bs + Cfg::BN * LDK);
+    int* cnt = reinterpret_cast<int*>(thr + Cfg::BN);
+    int* flags = cnt + Cfg::BN;  // [0],[1]: alternating "some candidate did not fit" flags
+    u64* list = reinterpret_cast<u64*>(flags + 4);
+    u64* queue = list + (size_t)Cfg::BN * k;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // consecutive logical ids share a catalog chunk (and hence an XCD's L2)
+    const int chunk = bid / n_qtiles, qtile = bid % n_qtiles;
+    const int q0 = qtile * Cfg::BN;
+
+    for (int i = tid; i < Cfg::BN; i += Cfg::THREADS) { thr[i] = 0ull; cnt[i] = 0; }
+    for (int i = tid; i < Cfg::BN * k; i += Cfg::THREADS) list[i] = 0ull;
+    if (tid < 4) flags[tid] = 0;
+    __syncthreads();
+
+    // this lane's queries: column (lane & 31) of each of its TN column tiles
+    int myq[Cfg::TN];
+    u64 mythr[Cfg::TN];
+    int ex_lo[Cfg::TN], ex_hi[Cfg::TN];
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+        myq[j] = (wn * Cfg::TN + j) * 32 + (lane & 31);
+        mythr[j] = 0ull;
+        const int gq = q0 + myq[j];
+        ex_lo[j] = ex_hi[j] = 0;
+        if (excl_off != nullptr && gq < Q) { ex_lo[j] = excl_off[gq]; ex_hi[j] = excl_off[gq + 1]; }
+    }
+
+    const int t_begin = chunk * tiles_per_chunk;
+    const int t_end = min(n_row_tiles, t_begin + tiles_per_chunk);
+    int round = 0;
+    TileRegs<Cfg> pre;
+    f32x16 acc[Cfg::TM][Cfg::TN];
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int64_t row0 = (int64_t)tile * Cfg::BM;
+        tile_gemm<Cfg>(acc, P, row0, N, Qn, q0, Qpad, K, As, Bs, pre, false);
+
+        if (EMIT) {
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t row = row0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
+                        const int gq = q0 + myq[j];
+                        if (row < N && gq < Q) scores_out[(int64_t)gq * N + row] = acc[i][j][e] + 0.0f;
+                    }
+        }
+
+        // ---- selection: push every score that beats its query's current k-th best
+        // pend bit (j*TM+i)*16+e: score e of accumulator tile (i,j) still has to be offered
+        unsigned long long pend = 0ull;
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const float thr_s = mythr[j] ? key_score(mythr[j]) : -INFINITY;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (acc[i][j][e] + 0.0f >= thr_s) pend |= 1ull << ((j * Cfg::TM + i) * 16 + e);
+        }
+        bool more;
+        do {
+            bool lane_pending = false;
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i) {
+                    const int sh = (j * Cfg::TM + i) * 16;
+                    unsigned m16 = (unsigned)(pend >> sh) & 0xFFFFu;
+                    while (m16) {
+                        const int e = __builtin_ctz(m16);
+                        m16 &= m16 - 1;
+                        float s = acc[i][j][0];
+#pragma unroll
+                        for (int t = 1; t < 16; ++t) s = e == t ? acc[i][j][t] : s;
+                        s = s + 0.0f;  // -0 -> +0
+                        const int64_t row = row0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
+                        bool take = row < N;
+                        u64 key = 0ull;
+                        if (take) {
+                            key = make_key(s, row_base + (uint32_t)row);
+                            take = key > mythr[j];
+                        }
+                        if (take && ex_hi[j] > ex_lo[j]) take = !excluded(excl_idx, ex_lo[j], ex_hi[j], (int)row);
+                        bool settled = true;
+                        if (take) {
+                            const int slot = atomicAdd(&cnt[myq[j]], 1);
+                            if (slot < QCAP) queue[myq[j] * QCAP + slot] = key;
+                            else { settled = false; lane_pending = true; }
+                        }
+                        if (settled) pend &= ~(1ull << (sh + e));
+                    }
+                }
+            if (lane_pending) flags[round & 1] = 1;
+            __syncthreads();
+            more = flags[round & 1] != 0;
+            if (tid == 0) flags[(round + 1) & 1] = 0;
+            // each wave merges the queues of its share of the queries
+            for (int q = wave; q < Cfg::BN; q += Cfg::THREADS / 64) {
+                const int c = cnt[q];
+                if (c > 0) {
+                    merge_queue(list + (size_t)q * k, queue + q * QCAP, c < QCAP ? c : QCAP, k, lane);
+                    if (lane == 0) { thr[q] = list[(size_t)q * k + k - 1]; cnt[q] = 0; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) mythr[j] = thr[myq[j]];
+            ++round;
+        } while (more);
+    }
+
+    // sorted partial lists out
+    for (int i = tid; i < Cfg::BN * k; i += Cfg::THREADS) {
+        const int q = i / k, e = i % k;
+        partial[((size_t)chunk * Qpad + q0 + q) * k + e] = list[(size_t)q * k + e];
+    }
+}
+
+// ---------------------------------------------------------------- k-way merge of sorted lists
+// keys: [n_lists][q_stride][k] sorted descending per (list, query); one wavefront per query
+// runs a tournament: every lane holds the heads of up to 4 lists.
+constexpr int MERGE_LPL = 4;  // lists per lane => at most 256 lists
+__global__ __launch_bounds__(256) void merge_kernel(const u64* __restrict__ keys, int n_lists, int q_stride, int Q,
+                                                    int k, int64_t* __restrict__ out_idx,
+                                                    float* __restrict__ out_score, u64* __restrict__ out_keys) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    u64 head[MERGE_LPL];
+    int pos[MERGE_LPL];
+#pragma unroll
+    for (int s = 0; s < MERGE_LPL; ++s) {
+        const int c = lane + 64 * s;
+        pos[s] = 0;
+        head[s] = c < n_lists ? keys[((size_t)c * q_stride + q) * k] : 0ull;
+    }
+    for (int e = 0; e < k; ++e) {
+        u64 best = 0ull;
+#pragma unroll
+        for (int s = 0; s < MERGE_LPL; ++s) best = head[s] > best ? head[s] : best;
+        const u64 w = wave_max_u64(best);
+        if (w != 0ull) {
+#pragma unroll
+            for (int s = 0; s < MERGE_LPL; ++s) {
+                if (head[s] == w) {  // keys are unique: exactly one (lane, s) advances
+                    const int c = lane + 64 * s;
+                    ++pos[s];
+                    head[s] = pos[s] < k ? keys[((size_t)c * q_stride + q) * k + pos[s]] : 0ull;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (out_keys) out_keys[(size_t)q * k + e] = w;
+            if (out_idx) {
+                out_idx[(size_t)q * k + e] = w ? (int64_t)key_row(w) : -1;
+                out_score[(size_t)q * k + e] = w ? key_score(w) : 0.0f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct Index {
+    float* rows = nullptr;  // normalised [n_rows, dim]
+    int64_t n_rows = 0;
+    int dim = 0;
+    int64_t row_offset = 0;
+    int device = 0;
+    int n_cu = 256;
+};
+
+typedef TileCfg<2, 2, 2, 2> CfgBig;    // 128 rows x 128 queries
+typedef TileCfg<4, 1, 2, 2> CfgMid;    // 256 rows x  64 queries
+typedef TileCfg<4, 1, 2, 1> CfgSmall;  // 256 rows x  32 queries
+
+struct Plan {
+    int variant;  // 0 big, 1 mid, 2 small
+    int BM, BN, Qpad, n_qtiles, n_row_tiles, tiles_per_chunk, n_chunks;
+    size_t smem;
+    size_t ws_q, ws_partial, ws_total;
+};
+
+static Plan make_plan(const Index* ix, int Q, int k) {
+    Plan p;
+    if (Q > 64 && k <= 32) { p.variant = 0; p.BM = CfgBig::BM; p.BN = CfgBig::BN; p.smem = SearchSmem<CfgBig>::bytes(k); }
+    else if (Q > 32 && k <= 64) { p.variant = 1; p.BM = CfgMid::BM; p.BN = CfgMid::BN; p.smem = SearchSmem<CfgMid>::bytes(k); }
+    else { p.variant = 2; p.BM = CfgSmall::BM; p.BN = CfgSmall::BN; p.smem = SearchSmem<CfgSmall>::bytes(k); }
+    p.n_qtiles = (Q + p.BN - 1) / p.BN;
+    p.Qpad = p.n_qtiles * p.BN;
+    p.n_row_tiles = (int)((ix->n_rows + p.BM - 1) / p.BM);
+    // aim for ~3 resident blocks per CU over the whole grid, at most 256 chunks (merge_kernel limit)
+    int want_chunks = (3 * ix->n_cu + p.n_qtiles - 1) / p.n_qtiles;
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > 256) want_chunks = 256;
+    if (want_chunks > p.n_row_tiles) want_chunks = p.n_row_tiles;
+    p.tiles_per_chunk = (p.n_row_tiles + want_chunks - 1) / want_chunks;
+    p.n_chunks = (p.n_row_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    p.ws_q = ((size_t)p.Qpad * ix->dim * 4 + 255) & ~(size_t)255;
+    p.ws_partial = ((size_t)p.n_chunks * p.Qpad * k * 8 + 255) & ~(size_t)255;
+    p.ws_total = p.ws_q + p.ws_partial;
+    return p;
+}
+
+template <class Cfg, bool EMIT>
+static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q, int k, const int32_t* ei,
+                         const int32_t* eo, u64* partial, float* scores_out, hipStream_t st) {
+    auto kern = search_kernel<Cfg, EMIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+        attr_set = true;
+    }
+    const int grid = p.n_chunks * p.n_qtiles;
+    {
+        ScopedTimer tm(T_SEARCH_KERNEL, st);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), p.smem, st, ix->rows, ix->n_rows, ix->dim, qn, p.Qpad,
+                           Q, k, ei, eo, (uint32_t)ix->row_offset, p.n_row_tiles, p.tiles_per_chunk, p.n_qtiles,
+                           partial, scores_out);
+    }
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
+}
+
+static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei, const int32_t* eo, int64_t* out_idx,
+                      float* out_score, u64* out_keys, float* scores_out, void* ws, size_t ws_bytes, hipStream_t st) {
+    ICREC_REQUIRE(ix && q, "icrec_search: NULL index or queries");
+    ICREC_REQUIRE(Q >= 1, "icrec_search: n_queries must be >= 1 (got %d)", Q);
+    ICREC_REQUIRE(k >= 1 && k <= ICREC_MAX_K, "icrec_search: k must be in [1, %d] (got %d)", ICREC_MAX_K, k);
+    ICREC_REQUIRE((ei == nullptr) == (eo == nullptr), "icrec_search: excl_idx and excl_off must both be set or both NULL");
+    const Plan p = make_plan(ix, Q, k);
+    if (ws_bytes < p.ws_total || ws == nullptr) {
+        set_error("icrec_search: workspace too small (%zu < %zu)", ws_bytes, p.ws_total);
+        return ICREC_ENOMEM;
+    }
+    ICREC_HIP(hipSetDevice(ix->device));
+    ScopedTimer whole(T_SEARCH, st);
+    float* qn = reinterpret_cast<float*>(ws);
+    u64* partial = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + p.ws_q);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((p.Qpad + 3) / 4), dim3(256), 0, st, q, qn, (int64_t)Q,
+                       (int64_t)p.Qpad, ix->dim, 1e-12f);
+    int rc;
+    if (scores_out) {
+        rc = p.variant == 0 ? launch_search<CfgBig, true>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
+           : p.variant == 1 ? launch_search<CfgMid, true>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
+                            : launch_search<CfgSmall, true>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st);
+    } else {
+        rc = p.variant == 0 ? launch_search<CfgBig, false>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
+           : p.variant == 1 ? launch_search<CfgMid, false>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
+                            : launch_search<CfgSmall, false>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st);
+    }
+    if (rc != ICREC_OK) return rc;
+    if (out_idx || out_keys) {
+        hipLaunchKernelGGL(merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k, out_idx,
+                           out_score, out_keys);
+        ICREC_HIP(hipGetLastError());
+    }
+    return ICREC_OK;
+}
+
+}  // namespace icrec
+
+using namespace icrec;
+
+extern "C" {
+
+int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim, int64_t row_offset, int device,
+                       icrec_index** out) {
+    ICREC_REQUIRE(rows_dev && out, "icrec_index_create: NULL argument");
+    ICREC_REQUIRE(n_rows >= 1, "icrec_index_create: n_rows must be >= 1");
+    ICREC_REQUIRE(dim >= BK && dim % BK == 0 && dim <= 4096, "icrec_index_create: dim must be a multiple of %d (got %d)", BK, dim);
+    ICREC_REQUIRE(row_offset >= 0 && row_offset + n_rows < 0xFFFFFFFFll, "icrec_index_create: row_offset + n_rows must be < 2^32-1");
+    ICREC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ICREC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("icrec_index_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+        return ICREC_ENODEV;
+    }
+    Index* ix = new Index();
+    ix->n_rows = n_rows; ix->dim = dim; ix->row_offset = row_offset; ix->device = device;
+    ix->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipMalloc(&ix->rows, (size_t)n_rows * dim * sizeof(float));
+    if (e != hipSuccess) {
+        delete ix;
+        set_error("icrec_index_create: hipMalloc of %zu bytes failed: %s", (size_t)n_rows * dim * 4, hipGetErrorString(e));
+        return ICREC_ENOMEM;
+    }
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, 0, rows_dev, ix->rows,
+                       n_rows, n_rows, dim, 1e-12f);
+    ICREC_HIP(hipGetLastError());
+    ICREC_HIP(hipStreamSynchronize(0));
+    *out = reinterpret_cast<icrec_index*>(ix);
+    return ICREC_OK;
+}
+
+int icrec_index_destroy(icrec_index* h) {
+    Index* ix = reinterpret_cast<Index*>(h);
+    if (!ix) return ICREC_OK;
+    hipSetDevice(ix->device);
+    hipFree(ix->rows);
+    delete ix;
+    return ICREC_OK;
+}
+
+int64_t icrec_index_rows(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->n_rows : 0; }
+
+int icrec_index_export(const icrec_index* h, float* rows_dev, void* stream) {
+    const Index* ix = reinterpret_cast<const Index*>(h);
+    ICREC_REQUIRE(ix && rows_dev, "icrec_index_export: NULL argument");
+    ICREC_HIP(hipMemcpyAsync(rows_dev, ix->rows, (size_t)ix->n_rows * ix->dim * 4, hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    return ICREC_OK;
+}
+
+size_t icrec_search_workspace_bytes(const icrec_index* h, int32_t n_queries, int32_t k) {
+    const Index* ix = reinterpret_cast<const Index*>(h);
+    if (!ix || n_queries < 1 || k < 1 || k > ICREC_MAX_K) return 0;
+    return make_plan(ix, n_queries, k).ws_total;
+}
+
+int icrec_search(icrec_index* h, const float* q_dev, int32_t n_queries, int32_t k, const int32_t* excl_idx_dev,
+                 const int32_t* excl_off_dev, int64_t* out_idx_dev, float* out_score_dev, void* ws, size_t ws_bytes,
+                 void* stream) {
+    ICREC_REQUIRE(out_idx_dev && out_score_dev, "icrec_search: NULL output");
+    return run_search(reinterpret_cast<Index*>(h), q_dev, n_queries, k, excl_idx_dev, excl_off_dev, out_idx_dev,
+                      out_score_dev, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int icrec_search_partial(icrec_index* h, const float* q_dev, int32_t n_queries, int32_t k, const int32_t* excl_idx_dev,
+                         const int32_t* excl_off_dev, uint64_t* out_keys_dev, void* ws, size_t ws_bytes, void* stream) {
+    ICREC_REQUIRE(out_keys_dev, "icrec_search_partial: NULL output");
+    return run_search(reinterpret_cast<Index*>(h), q_dev, n_queries, k, excl_idx_dev, excl_off_dev, nullptr, nullptr,
+                      reinterpret_cast<u64*>(out_keys_dev), nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int icrec_scores(icrec_index* h, const float* q_dev, int32_t n_queries, float* out_dev, void* ws, size_t ws_bytes,
+                 void* stream) {
+    ICREC_REQUIRE(out_dev, "icrec_scores: NULL output");
+    return run_search(reinterpret_cast<Index*>(h), q_dev, n_queries, 1, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      out_dev, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists, int32_t n_queries, int32_t k, int64_t* out_idx_dev,
+                     float* out_score_dev, int device, void* stream) {
+    ICREC_REQUIRE(keys_dev && out_idx_dev && out_score_dev, "icrec_merge_topk: NULL argument");
+    ICREC_REQUIRE(n_lists >= 1 && n_lists <= 64 * MERGE_LPL, "icrec_merge_topk: n_lists must be in [1, %d]", 64 * MERGE_LPL);
+    ICREC_REQUIRE(n_queries >= 1 && k >= 1 && k <= ICREC_MAX_K, "icrec_merge_topk: bad n_queries/k");
+    ICREC_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(merge_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u64*>(keys_dev), n_lists, n_queries, n_queries, k, out_idx_dev,
+                       out_score_dev, (u64*)nullptr);
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
+}
+
+int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n_rows, int32_t dim, float eps, int device,
+                         void* stream) {
+    ICREC_REQUIRE(x_dev && out_dev && n_rows >= 1 && dim >= 1, "icrec_normalize_rows: bad argument");
+    ICREC_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x_dev, out_dev, n_rows, n_rows, dim, eps);
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
+}
+
+}  // extern "C"
