@@ -1,10 +1,486 @@
-// encoder.hip — placeholder until the encoder kernels land (next commit).
+// encoder.hip — the SentenceTransformer forward on gfx950: BertModel (6 post-LN layers),
+// masked mean pooling, L2 normalisation; token-packed (varlen), fp32 throughout, every GEMM
+// and both attention products on v_mfma_f32_32x32x2_f32.
+//
+// Replaces the device work of SentenceTransformer.encode as called at
+//   /root/reference/src/inference/serve_recommendations.py:195-200 (catalog index build)
+//   /root/reference/src/inference/serve_recommendations.py:213, :246 (per-request query)
+// Arithmetic follows transformers/models/bert/modeling_bert.py (tf:) as cited per kernel,
+// and oracle/icrec_oracle.c reduction orders where a kernel says "oracle order".
 #include "common.h"
-using namespace icrec;
-extern "C" {
-size_t icrec_encoder_weight_count(const icrec_bert_cfg*) { return 0; }
-int icrec_encoder_create(const float*, size_t, const icrec_bert_cfg*, int, icrec_encoder**) { set_error("encoder not built yet"); return ICREC_EINVAL; }
-int icrec_encoder_destroy(icrec_encoder*) { return ICREC_OK; }
-size_t icrec_encode_workspace_bytes(const icrec_encoder*, int64_t, int32_t) { return 0; }
-int icrec_encode(icrec_encoder*, const int32_t*, const int32_t*, int32_t, int64_t, int32_t, float*, void*, size_t, void*) { set_error("encoder not built yet"); return ICREC_EINVAL; }
+
+namespace icrec {
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ int find_seq(const int32_t* __restrict__ cu, int n_seqs, int t) {
+    int lo = 0, hi = n_seqs;  // largest s with cu[s] <= t
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
 }
+
+// LayerNorm of one 384-wide row held 6 values per lane (element i = lane + 64*j); oracle order.
+template <int H>
+__device__ __forceinline__ void ln_row(float (&v)[H / 64], const float* __restrict__ g, const float* __restrict__ b,
+                                       float eps, float* __restrict__ out, int lane) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H / 64; ++j) s = s + v[j];
+    const float mean = wave_sum_f32(s) / (float)H;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H / 64; ++j) {
+        float d = v[j] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float var = wave_sum_f32(q) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < H / 64; ++j) {
+        const int i = lane + 64 * j;
+        out[i] = fmaf((v[j] - mean) * rstd, g[i], b[i]);
+    }
+}
+
+// ---------------------------------------------------------------- K1: embeddings + LN (tf:98-107)
+template <int H>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids,
+                                                       const int32_t* __restrict__ cu, int n_seqs, int T,
+                                                       const float* __restrict__ word, const float* __restrict__ pos,
+                                                       const float* __restrict__ type, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float eps, int vocab, int max_pos,
+                                                       float* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int s = find_seq(cu, n_seqs, t);
+    int id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int p = t - cu[s];
+    p = p >= max_pos ? max_pos - 1 : p;
+    float v[H / 64];
+#pragma unroll
+    for (int j = 0; j < H / 64; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = (word[(size_t)id * H + i] + type[i]) + pos[(size_t)p * H + i];
+    }
+    ln_row<H>(v, g, b, eps, x + (size_t)t * H, lane);
+}
+
+// ---------------------------------------------------------------- residual + LN (tf:292, tf:350)
+// x <- LN(a + x); `a` already holds dense(.) + bias.
+template <int H>
+__global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a, float* __restrict__ x, int T,
+                                                     const float* __restrict__ g, const float* __restrict__ b,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float v[H / 64];
+#pragma unroll
+    for (int j = 0; j < H / 64; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = a[(size_t)t * H + i] + x[(size_t)t * H + i];
+    }
+    ln_row<H>(v, g, b, eps, x + (size_t)t * H, lane);
+}
+
+// ---------------------------------------------------------------- GEMM: out = A . W^T + bias [, GELU]
+// torch.nn.Linear (tf:175-177 QKV, tf:290 attention output, tf:335 intermediate, tf:348 output).
+// GELU is the exact erf form (tf:336, ACT2FN["gelu"]).
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <class Cfg, bool GELU>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __restrict__ A, int M, int K,
+                                                                 const float* __restrict__ W, int N,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int n_tiles_n) {
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
+    float* As = smem;
+    float* Bs = smem + Cfg::BM * LDK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_tiles_n, nt = bid % n_tiles_n;  // tiles sharing an A row panel are neighbours
+    const int64_t m0 = (int64_t)mt * Cfg::BM, n0 = (int64_t)nt * Cfg::BN;
+    TileRegs<Cfg> pre;
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    tile_gemm<Cfg>(acc, A, m0, M, W, n0, N, K, As, Bs, pre, false);
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+        const int64_t col = n0 + (wn * Cfg::TN + j) * 32 + (lane & 31);
+        const float bv = col < N ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
+                if (row < M && col < N) {
+                    float v = acc[i][j][e] + bv;
+                    if (GELU) v = gelu_erf(v);
+                    out[row * N + col] = v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------- attention (tf:111-136, 164-203)
+// One workgroup = one (sequence, head) and up to four 32-row query blocks (one per wave).
+// S^T = K.Q^T is computed with keys on the accumulator rows, so each lane ends up with the
+// scores of ONE query (column = lane & 31) against 16 keys per 32-key tile.  The softmax is
+// then lane-local plus one exchange with lane^32, and the exponentiated accumulator registers
+// are fed back unchanged as the A operand of P.V (A[i=query][k=key]): no transpose, no LDS
+// round trip.  Key order inside the P.V chain is therefore, per 32-key tile,
+//   e = 0..15: key (e&3)+8(e>>2) then key (e&3)+8(e>>2)+4
+// and the softmax denominator is the sum of the two half-wave partial sums; the oracle
+// (icrec_oracle.c, attention block) accumulates in exactly this order.
+constexpr int DH = 32;
+constexpr int LDQ = 36;  // Q/K LDS row stride (even/odd split layout, like the GEMM tiles)
+
+template <int NKT>  // max 32-key tiles per sequence in this launch (1, 2, 4, 8)
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                        int heads, int H, float scale, float* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) float smem_att[];
+    float* Ks = smem_att;                 // [NKT*32][LDQ]
+    float* Vs = Ks + NKT * 32 * LDQ;      // [NKT*32][32]
+    float* Qs = Vs + NKT * 32 * DH;       // [128][LDQ]
+    float* Ls = Qs + 128 * LDQ;           // [4][32] softmax denominators per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int t0 = cu[s], L = cu[s + 1] - t0;
+    const int qb0 = blockIdx.y * 4;       // first query block of this workgroup
+    if (qb0 * 32 >= L) return;
+    const int nkt = (L + 31) >> 5;
+    const int ld = 3 * H;
+
+    // stage K, V (all keys) and this workgroup's Q rows; rows past L are clamped to row L-1
+    // (their scores are masked to -inf / their outputs never stored).
+    for (int id = tid; id < nkt * 32 * 8; id += 256) {
+        const int row = id >> 3, c = id & 7;
+        const int rr = row < L ? row : L - 1;
+        const float* src = qkv + (size_t)(t0 + rr) * ld + hd * DH + c * 4;
+        const float4 kv = *reinterpret_cast<const float4*>(src + H);
+        const float4 vv = *reinterpret_cast<const float4*>(src + 2 * H);
+        float* kp = Ks + row * LDQ + (c >> 1) * 8 + (c & 1) * 2;
+        *reinterpret_cast<float2*>(kp) = make_float2(kv.x, kv.z);
+        *reinterpret_cast<float2*>(kp + 4) = make_float2(kv.y, kv.w);
+        *reinterpret_cast<float4*>(Vs + row * DH + c * 4) = vv;
+    }
+    for (int id = tid; id < 128 * 8; id += 256) {
+        const int row = id >> 3, c = id & 7;
+        int rr = qb0 * 32 + row;
+        rr = rr < L ? rr : L - 1;
+        const float4 qv = *reinterpret_cast<const float4*>(qkv + (size_t)(t0 + rr) * ld + hd * DH + c * 4);
+        float* qp = Qs + row * LDQ + (c >> 1) * 8 + (c & 1) * 2;
+        *reinterpret_cast<float2*>(qp) = make_float2(qv.x, qv.z);
+        *reinterpret_cast<float2*>(qp + 4) = make_float2(qv.y, qv.w);
+    }
+    __syncthreads();
+
+    const int qb = qb0 + wave;
+    if (qb * 32 >= L) return;  // whole wave idle (no further barriers below)
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- S^T tiles: acc[kt][e] = sum_d K[kt*32+krow(e)][d] * Q[qb*32 + r][d]
+    f32x16 sc[NKT];
+    float4 qf[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) qf[kq] = *reinterpret_cast<const float4*>(Qs + (wave * 32 + r) * LDQ + kq * 8 + h * 4);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
+        if (kt < nkt) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 32 + r) * LDQ + kq * 8 + h * 4);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kq].x, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kq].y, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kq].z, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kq].w, sc[kt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- scale, mask the key tail, row max (lane-local, then with the other half-wave)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + acc_row(e, lane);
+            const float v = key < L ? sc[kt][e] * scale : -INFINITY;
+            sc[kt][e] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- exponentiate; denominator = this half-wave's keys ascending, then the two halves added
+    float lsum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = (kt < nkt) ? expf(sc[kt][e] - mx) : 0.0f;
+            sc[kt][e] = p;
+            if (kt < nkt) lsum = lsum + p;
+        }
+    {
+        const float other = __shfl_xor(lsum, 32, 64);
+        lsum = h == 0 ? lsum + other : other + lsum;  // l0 + l1 in both halves
+    }
+    if (h == 0) Ls[wave * 32 + r] = lsum;
+    // ---- O = P.V with P taken straight from the accumulator registers
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float vv = Vs[key * DH + r];
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], vv, o, 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise rows by their denominator and store (row = query, column = head dim)
+    // (Ls was written by this wave's own lanes; wave-local LDS ordering makes it visible.)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int qrow = acc_row(e, lane);
+        const int tq = qb * 32 + qrow;
+        if (tq < L) ctx[(size_t)(t0 + tq) * H + hd * DH + r] = o[e] / Ls[wave * 32 + qrow];
+    }
+}
+
+// ---------------------------------------------------------------- mean pooling + L2 normalise
+// sentence_transformers Pooling(mean): sum_t h_t / clamp(count, 1e-9); then n_norm times
+// x / max(|x|_2, 1e-12) (Normalize module, normalize_embeddings=True).  One workgroup of
+// H threads per sequence; norm in oracle order by wave 0.
+template <int H>
+__global__ __launch_bounds__(H) void pool_norm_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+                                                      int n_norm, float* __restrict__ out) {
+    __shared__ float v[H];
+    __shared__ float den_s;
+    const int s = blockIdx.x, i = threadIdx.x;
+    const int t0 = cu[s], t1 = cu[s + 1];
+    float acc = 0.0f;
+    for (int t = t0; t < t1; ++t) acc = acc + x[(size_t)t * H + i];
+    float cnt = (float)(t1 - t0);
+    cnt = cnt < 1e-9f ? 1e-9f : cnt;
+    float val = acc / cnt;
+    for (int rep = 0; rep < n_norm; ++rep) {
+        v[i] = val;
+        __syncthreads();
+        if (i < 64) {
+            float a = 0.0f;
+#pragma unroll
+            for (int j = 0; j < H / 64; ++j) a = fmaf(v[i + 64 * j], v[i + 64 * j], a);
+            const float nrm = sqrtf(wave_sum_f32(a));
+            if (i == 0) den_s = nrm > 1e-12f ? nrm : 1e-12f;
+        }
+        __syncthreads();
+        val = val / den_s;
+        __syncthreads();
+    }
+    out[(size_t)s * H + i] = val;
+}
+
+// ---------------------------------------------------------------- host side
+constexpr int HID = 384;
+
+struct LayerW {
+    float *Wqkv, *bqkv, *Wo, *bo, *g1, *b1n, *W1, *b1, *W2, *b2, *g2, *b2n;
+};
+struct Encoder {
+    icrec_bert_cfg cfg;
+    int device = 0;
+    float* blob = nullptr;   // the uploaded weight blob
+    float* extra = nullptr;  // repacked Wqkv / bqkv
+    float *word, *pos, *type, *eg, *eb;
+    LayerW layers[64];
+};
+
+static size_t weight_count(const icrec_bert_cfg* c) {
+    const size_t H = c->hidden, I = c->intermediate;
+    const size_t emb = (size_t)c->vocab_size * H + (size_t)c->max_position * H + (size_t)c->type_vocab * H + 2 * H;
+    const size_t per = 4 * (H * H + H) + 2 * H + (I * H + I) + (H * I + H) + 2 * H;
+    return emb + per * c->layers;
+}
+
+struct EncWs {
+    size_t x, qkv, ctx, t1, h, total;
+};
+static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T) {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    EncWs w;
+    size_t o = 0;
+    w.x = o;   o += al((size_t)T * c.hidden * 4);
+    w.qkv = o; o += al((size_t)T * 3 * c.hidden * 4);
+    w.ctx = o; o += al((size_t)T * c.hidden * 4);
+    w.t1 = o;  o += al((size_t)T * c.hidden * 4);
+    w.h = o;   o += al((size_t)T * c.intermediate * 4);
+    w.total = o;
+    return w;
+}
+
+typedef TileCfg<2, 2, 2, 2> GemmBig;  // 128 x 128 output tile, 4 waves
+
+template <bool GELU>
+static void launch_linear(const float* A, int M, int K, const float* W, int N, const float* bias, float* out,
+                          hipStream_t st) {
+    const int mt = (M + GemmBig::BM - 1) / GemmBig::BM, nt = (N + GemmBig::BN - 1) / GemmBig::BN;
+    hipLaunchKernelGGL((linear_kernel<GemmBig, GELU>), dim3(mt * nt), dim3(GemmBig::THREADS), 0, st, A, M, K, W, N,
+                       bias, out, nt);
+}
+
+template <int NKT>
+static int launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
+                            float* ctx, hipStream_t st) {
+    const size_t smem = (size_t)(NKT * 32 * LDQ + NKT * 32 * DH + 128 * LDQ + 128) * sizeof(float);
+    auto kern = attention_kernel<NKT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+        attr_set = true;
+    }
+    const int qgroups = (max_seqlen + 127) / 128;
+    hipLaunchKernelGGL(kern, dim3(n_seqs * heads, qgroups), dim3(256), smem, st, qkv, cu, heads, H,
+                       1.0f / sqrtf((float)DH), ctx);
+    return ICREC_OK;
+}
+
+}  // namespace icrec
+
+using namespace icrec;
+
+extern "C" {
+
+size_t icrec_encoder_weight_count(const icrec_bert_cfg* cfg) { return cfg ? weight_count(cfg) : 0; }
+
+int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec_bert_cfg* cfg, int device,
+                         icrec_encoder** out) {
+    ICREC_REQUIRE(weights_host && cfg && out, "icrec_encoder_create: NULL argument");
+    ICREC_REQUIRE(cfg->hidden == HID, "icrec_encoder_create: this build supports hidden=384 only (got %d)", cfg->hidden);
+    ICREC_REQUIRE(cfg->heads * DH == cfg->hidden, "icrec_encoder_create: head_dim must be 32 (heads=%d)", cfg->heads);
+    ICREC_REQUIRE(cfg->intermediate >= 128 && cfg->intermediate % BK == 0, "icrec_encoder_create: bad intermediate size %d", cfg->intermediate);
+    ICREC_REQUIRE(cfg->layers >= 1 && cfg->layers <= 64, "icrec_encoder_create: layers must be in [1,64]");
+    ICREC_REQUIRE(cfg->vocab_size >= 1 && cfg->max_position >= 1 && cfg->type_vocab >= 1, "icrec_encoder_create: bad vocab/position sizes");
+    ICREC_REQUIRE(cfg->n_normalize >= 0 && cfg->n_normalize <= 4, "icrec_encoder_create: n_normalize must be in [0,4]");
+    ICREC_REQUIRE(n_floats == weight_count(cfg), "icrec_encoder_create: weight blob has %zu floats, expected %zu", n_floats, weight_count(cfg));
+    ICREC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ICREC_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("icrec_encoder_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+        return ICREC_ENODEV;
+    }
+    Encoder* e = new Encoder();
+    e->cfg = *cfg;
+    e->device = device;
+    const size_t H = cfg->hidden, I = cfg->intermediate;
+    if (hipMalloc(&e->blob, n_floats * 4) != hipSuccess ||
+        hipMalloc(&e->extra, (size_t)cfg->layers * (3 * H * H + 3 * H) * 4) != hipSuccess) {
+        set_error("icrec_encoder_create: hipMalloc failed");
+        if (e->blob) (void)hipFree(e->blob);
+        delete e;
+        return ICREC_ENOMEM;
+    }
+    ICREC_HIP(hipMemcpy(e->blob, weights_host, n_floats * 4, hipMemcpyHostToDevice));
+    float* p = e->blob;
+    e->word = p; p += (size_t)cfg->vocab_size * H;
+    e->pos = p;  p += (size_t)cfg->max_position * H;
+    e->type = p; p += (size_t)cfg->type_vocab * H;
+    e->eg = p;   p += H;
+    e->eb = p;   p += H;
+    float* x = e->extra;
+    for (int l = 0; l < cfg->layers; ++l) {
+        LayerW& L = e->layers[l];
+        L.Wqkv = x; x += 3 * H * H;
+        L.bqkv = x; x += 3 * H;
+        for (int part = 0; part < 3; ++part) {  // Wq,bq | Wk,bk | Wv,bv are interleaved in the blob
+            ICREC_HIP(hipMemcpy(L.Wqkv + part * H * H, p, H * H * 4, hipMemcpyDeviceToDevice)); p += H * H;
+            ICREC_HIP(hipMemcpy(L.bqkv + part * H, p, H * 4, hipMemcpyDeviceToDevice)); p += H;
+        }
+        L.Wo = p; p += H * H; L.bo = p; p += H;
+        L.g1 = p; p += H; L.b1n = p; p += H;
+        L.W1 = p; p += I * H; L.b1 = p; p += I;
+        L.W2 = p; p += H * I; L.b2 = p; p += H;
+        L.g2 = p; p += H; L.b2n = p; p += H;
+    }
+    ICREC_HIP(hipDeviceSynchronize());
+    *out = reinterpret_cast<icrec_encoder*>(e);
+    return ICREC_OK;
+}
+
+int icrec_encoder_destroy(icrec_encoder* h) {
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    if (!e) return ICREC_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->blob);
+    (void)hipFree(e->extra);
+    delete e;
+    return ICREC_OK;
+}
+
+size_t icrec_encode_workspace_bytes(const icrec_encoder* h, int64_t total_tokens, int32_t n_seqs) {
+    const Encoder* e = reinterpret_cast<const Encoder*>(h);
+    if (!e || total_tokens < 1 || n_seqs < 1) return 0;
+    return enc_ws(e->cfg, total_tokens).total;
+}
+
+int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev, int32_t n_seqs, int64_t T64,
+                 int32_t max_seqlen, float* out_dev, void* ws, size_t ws_bytes, void* stream) {
+    Encoder* e = reinterpret_cast<Encoder*>(h);
+    ICREC_REQUIRE(e && ids_dev && cu_dev && out_dev, "icrec_encode: NULL argument");
+    ICREC_REQUIRE(n_seqs >= 1 && T64 >= n_seqs && T64 < (1ll << 31), "icrec_encode: bad n_seqs/total_tokens (%d, %lld)", n_seqs, (long long)T64);
+    ICREC_REQUIRE(max_seqlen >= 1 && max_seqlen <= 256 && max_seqlen <= e->cfg.max_position, "icrec_encode: max_seqlen must be in [1, 256] (got %d)", max_seqlen);
+    const int T = (int)T64;
+    const EncWs w = enc_ws(e->cfg, T);
+    if (!ws || ws_bytes < w.total) {
+        set_error("icrec_encode: workspace too small (%zu < %zu)", ws_bytes, w.total);
+        return ICREC_ENOMEM;
+    }
+    ICREC_HIP(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    ScopedTimer whole(T_ENCODE, st);
+    char* base = reinterpret_cast<char*>(ws);
+    float* x = reinterpret_cast<float*>(base + w.x);
+    float* qkv = reinterpret_cast<float*>(base + w.qkv);
+    float* ctx = reinterpret_cast<float*>(base + w.ctx);
+    float* t1 = reinterpret_cast<float*>(base + w.t1);
+    float* hb = reinterpret_cast<float*>(base + w.h);
+    const icrec_bert_cfg& c = e->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    const int rows_grid = (T + 3) / 4;
+
+    hipLaunchKernelGGL(embed_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T, e->word,
+                       e->pos, e->type, e->eg, e->eb, c.ln_eps, c.vocab_size, c.max_position, x);
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerW& L = e->layers[l];
+        launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
+        int rc;
+        if (max_seqlen <= 32) rc = launch_attention<1>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
+        else if (max_seqlen <= 64) rc = launch_attention<2>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
+        else if (max_seqlen <= 128) rc = launch_attention<4>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
+        else rc = launch_attention<8>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
+        if (rc != ICREC_OK) return rc;
+        launch_linear<false>(ctx, T, H, L.Wo, H, L.bo, t1, st);
+        hipLaunchKernelGGL(add_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n, c.ln_eps);
+        {
+            ScopedTimer tm(T_FFN_UP, st);
+            launch_linear<true>(x, T, H, L.W1, I, L.b1, hb, st);
+        }
+        launch_linear<false>(hb, T, I, L.W2, H, L.b2, t1, st);
+        hipLaunchKernelGGL(add_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n, c.ln_eps);
+    }
+    hipLaunchKernelGGL(pool_norm_kernel<HID>, dim3(n_seqs), dim3(HID), 0, st, x, cu_dev, c.n_normalize, out_dev);
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""Host side of the device encoder: SentenceTransformer.encode's GPU work.
+
+The reference calls `self.model.encode(texts, batch_size=64, normalize_embeddings=True)`
+(src/inference/serve_recommendations.py:195-200, :213, :246).  Here tokenisation is a
+separate host stage (tokenizer.py); this module takes token ids, packs them back to back
+(no padding), and runs libicrec's fp32-MFMA BERT forward + mean-pool + L2-normalise.
+
+torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+from .synthetic import BertShape
+
+MAX_SEQ_LEN = 256  # configs/train.yaml:11 (max_seq_length), also the attention kernel's limit
+
+
+def pack_token_ids(seqs: Sequence[Sequence[int]]):
+    """List of id lists -> (ids int32[T], cu_seqlens int32[n+1], max_len)."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    if len(seqs) == 0 or (lens < 1).any():
+        raise ValueError("every sequence needs at least one token")
+    if lens.max() > MAX_SEQ_LEN:
+        raise ValueError(f"sequence longer than max_seq_length={MAX_SEQ_LEN}; truncate on the host")
+    cu = np.zeros(len(seqs) + 1, np.int32)
+    np.cumsum(lens, out=cu[1:])
+    ids = np.concatenate([np.asarray(s, np.int32) for s in seqs]) if len(seqs) > 1 else np.asarray(seqs[0], np.int32)
+    return ids, cu, int(lens.max())
+
+
+class DeviceEncoder:
+    """all-MiniLM-L6-v2-shaped BERT encoder resident on one GPU."""
+
+    def __init__(self, weights: np.ndarray, shape: BertShape = BertShape(), device: str | torch.device = "cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.IcrecError("DeviceEncoder needs a CUDA/HIP device; there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.shape = shape
+        L = _native.lib()
+        self._cfg = _native.BertCfg(shape.vocab_size, shape.hidden, shape.layers, shape.heads, shape.intermediate,
+                                    shape.max_position, shape.type_vocab, shape.ln_eps, shape.n_normalize)
+        w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
+        want = int(L.icrec_encoder_weight_count(C.byref(self._cfg)))
+        if w.size != want:
+            raise ValueError(f"weight blob has {w.size} floats, expected {want} (layout: include/icrec.h)")
+        h = C.c_void_p()
+        _native.check(L.icrec_encoder_create(w.ctypes.data_as(C.c_void_p), w.size, C.byref(self._cfg),
+                                             self.device.index, C.byref(h)), "icrec_encoder_create")
+        self._h = h
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _native.lib().icrec_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _workspace(self, total_tokens: int, n_seqs: int) -> torch.Tensor:
+        need = int(_native.lib().icrec_encode_workspace_bytes(self._h, total_tokens, n_seqs))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_packed(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device tensors in (int32 ids[T], int32 cu_seqlens[n+1]) -> float32 [n, hidden] on the device."""
+        if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
+            raise TypeError("ids and cu_seqlens must be int32")
+        ids = ids.to(self.device).contiguous()
+        cu = cu_seqlens.to(self.device).contiguous()
+        n, T = int(cu.numel()) - 1, int(ids.numel())
+        if out is None:
+            out = torch.empty((n, self.shape.hidden), dtype=torch.float32, device=self.device)
+        ws = self._workspace(T, n)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _native.check(_native.lib().icrec_encode(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(cu.data_ptr()), n, T,
+                                                 int(max_seqlen), C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(ws.data_ptr()), ws.numel(), st), "icrec_encode")
+        return out
+
+    def encode_ids(self, seqs: Sequence[Sequence[int]], max_tokens_per_call: int = 1 << 18) -> torch.Tensor:
+        """Host token-id lists -> embeddings [n, hidden] on the device, in input order.
+        Long inputs are split into calls of at most `max_tokens_per_call` tokens."""
+        n = len(seqs)
+        out = torch.empty((n, self.shape.hidden), dtype=torch.float32, device=self.device)
+        start = 0
+        while start < n:
+            tok, end = 0, start
+            while end < n and (end == start or tok + len(seqs[end]) <= max_tokens_per_call):
+                tok += len(seqs[end])
+                end += 1
+            ids, cu, mx = pack_token_ids(seqs[start:end])
+            vmax = int(ids.max()) if ids.size else 0
+            if ids.min() < 0 or vmax >= self.shape.vocab_size:
+                raise ValueError(f"token id out of range [0, {self.shape.vocab_size})")
+            self.encode_packed(torch.from_numpy(ids).to(self.device, non_blocking=True),
+                               torch.from_numpy(cu).to(self.device, non_blocking=True), mx, out=out[start:end])
+            start = end
+        return out

@@ -39,6 +39,8 @@
  *   dot products / GEMM outputs : acc = 0; for k ascending: acc = fmaf(a[k], b[k], acc)
  *   row reductions over d elems : 64 strided partial sums (lane l takes l, l+64, ...),
  *                                 then a butterfly (xor 32,16,8,4,2,1)
+ *   attention P.V and softmax sum : the key order of the MFMA accumulator layout (see the
+ *                                 attention block below and csrc/encoder.hip:attention_kernel)
  * Ties in ranking: higher score first, then LOWER row index first (the
  * reference's torch.argsort(descending=True) is unstable on ties; this is the
  * build's own documented policy).
@@ -219,10 +221,16 @@ ORACLE_API int icrec_oracle_encode(const float* w, const oracle_bert_cfg* c, con
                 }
                 float lsum = l0 + l1;
                 float* ci = ctx + (size_t)(t0 + i) * H + h * DH;
+                /* P.V chain: per 32-key tile the keys enter in the order the kernel's
+                 * accumulator registers hold them (e = 0..15: key (e&3)+8(e>>2), then +4). */
                 for (int d = 0; d < DH; ++d) {
                     float acc = 0.0f;
-                    for (int j = 0; j < Ls; ++j)
-                        acc = fmaf(sc[j], v[(size_t)(t0 + j) * H + h * DH + d], acc);
+                    for (int kt = 0; kt * 32 < Ls; ++kt)
+                        for (int e = 0; e < 16; ++e)
+                            for (int hh = 0; hh < 2; ++hh) {
+                                int j = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                                if (j < Ls) acc = fmaf(sc[j], v[(size_t)(t0 + j) * H + h * DH + d], acc);
+                            }
                     ci[d] = acc / lsum;
                 }
             }
