@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — recommend() throughput on MI355X: SBERT encode -> cosine -> top-20 over the
+49,688-product catalog (BASELINE.json metric), with the kernel roofline and a CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload 49k7|10m]
+
+One "step" = one pass of the hot path over one batch of synthetic user contexts whose token
+ids are already resident in HBM: icrec_encode (BERT forward + pool + normalise) then
+icrec_search (cosine + top-20, exclusions off), results left in HBM.  At N > 1 (launched by
+torch.distributed.run, one rank per GPU, RCCL) the catalog is row-sharded, each rank encodes
+`--batch` contexts (weak scaling: global batch = N * batch), query embeddings and per-shard
+partial top-k lists are all-gathered and merged (instacart_next_order_recommendation_amd/sharded.py).
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+CATALOG_ROWS = 49_688  # notebooks/serve_recommendations.ipynb:101
+TOP_K = 20
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="user contexts per GPU per step")
+    ap.add_argument("--workload", default="49k7", choices=["49k7", "10m"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="queries in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
+    """The oracle (a C port of the reference's op sequence) on this box's host cores, on a bounded
+    sample of the same workload: encode n_sample contexts, then cos_sim (re-normalising the whole
+    catalog, as the reference does on every call) + full argsort + top-20 for each of them."""
+    from oracle import oracle
+
+    cfg = oracle.make_cfg(vocab_size=shape.vocab_size, n_normalize=shape.n_normalize)
+    cu_s = cu[: n_sample + 1]
+    ids_s = ids[: cu_s[-1]]
+    t0 = time.perf_counter()
+    emb = oracle.encode(weights, cfg, ids_s, cu_s)
+    t1 = time.perf_counter()
+    oracle.search(emb, catalog, TOP_K, None)
+    t2 = time.perf_counter()
+    return {"value": n_sample / (t2 - t0), "unit": "queries/s", "cores": oracle.threads(), "kind": "port",
+            "sample": f"{n_sample} of the step's contexts ({int(cu_s[-1])} tokens): oracle encode {t1 - t0:.2f}s + "
+                      f"cos_sim/argsort/top-{TOP_K} over {catalog.shape[0]} rows {t2 - t1:.2f}s (OpenMP C port, "
+                      f"batched; the reference serves one request at a time)"}
+
+
+def main() -> None:
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from instacart_next_order_recommendation_amd import _native, synthetic as syn
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+    from instacart_next_order_recommendation_amd.sharded import HipShardBackend, ShardedSearch, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    shape = syn.BertShape()
+    weights = syn.synthetic_bert_weights(shape, seed=0)
+    enc = DeviceEncoder(weights, shape, dev)
+
+    # ---- catalog shard (embedding-level synthetic: clustered unit vectors)
+    n_rows = CATALOG_ROWS if args.workload == "49k7" else 10_000_000
+    bounds = shard_bounds(n_rows, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    if args.workload == "49k7":
+        catalog = syn.synthetic_embeddings(n_rows, shape.hidden, seed=1)
+        shard = torch.from_numpy(catalog[lo:hi]).to(dev)
+    else:  # generated on the device per shard: 200 cluster centres + noise (fp32 rows)
+        catalog = None
+        g = torch.Generator(device=dev).manual_seed(1000 + rank)
+        centres = torch.randn(200, shape.hidden, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+        shard = torch.empty((hi - lo, shape.hidden), device=dev)
+        for s in range(0, hi - lo, 1 << 18):
+            m = min(1 << 18, hi - lo - s)
+            cid = torch.randint(0, 200, (m,), device=dev, generator=g)
+            shard[s:s + m] = centres[cid] + 0.35 * torch.randn(m, shape.hidden, device=dev, generator=g)
+    backend = HipShardBackend(shard, lo, dev)
+    del shard
+    search = ShardedSearch(backend, lo, hi)
+
+    # ---- this rank's batch of user contexts as packed token ids, resident in HBM
+    ids_h, cu_h = syn.synthetic_token_batch(args.batch, seed=1234 + rank)
+    max_len = int(np.diff(cu_h).max())
+    total_tokens = int(cu_h[-1])
+    ids_d = torch.from_numpy(ids_h).to(dev)
+    cu_d = torch.from_numpy(cu_h).to(dev)
+    emb = torch.empty((args.batch, shape.hidden), device=dev)
+
+    def step():
+        enc.encode_packed(ids_d, cu_d, max_len, out=emb)
+        return search.search(emb, TOP_K)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _native.timing_reset()
+    _native.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, sc = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _native.timing_enable(False)
+    ffn_ms, ffn_n = _native.timing_query(1)
+    enc_ms, _ = _native.timing_query(2)
+    srch_ms, _ = _native.timing_query(3)
+    skern_ms, _ = _native.timing_query(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- single-request latency (Q = 1, host-timed around the GPU call incl. the k*12-byte D2H)
+    p50_ms = None
+    if rank == 0 and world == 1:
+        lat = []
+        one_ids, one_cu = ids_d[: int(cu_h[1])], cu_d[:2]
+        one_emb = torch.empty((1, shape.hidden), device=dev)
+        for i in range(60):
+            torch.cuda.synchronize(dev)
+            a = time.perf_counter()
+            enc.encode_packed(one_ids, one_cu, int(cu_h[1]), out=one_emb)
+            i1, s1 = search.search(one_emb, TOP_K)
+            i1.cpu()
+            lat.append((time.perf_counter() - a) * 1e3)
+        p50_ms = float(np.median(lat[10:]))
+
+    if rank == 0:
+        q_per_step = args.batch * world
+        ms_per_step = elapsed / args.steps * 1e3
+        ffn_flops = 2.0 * total_tokens * shape.hidden * shape.intermediate  # algorithmic FLOPs per FFN-up launch
+        achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12 if ffn_ms > 0 else 0.0
+        out = {
+            "metric": "recommend_qps_top20_49k7_catalog" if args.workload == "49k7" else "recommend_qps_top20_10m_catalog",
+            "value": q_per_step * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[1]/[2]: encode + cos_sim + top-20 over the 49,688-row catalog, "
+                             f"{args.batch} user contexts per GPU per step") if args.workload == "49k7" else
+                            "BASELINE configs[4]: 10M x 384 fp32 synthetic catalog, row-sharded",
+                "catalog_rows": n_rows, "dim": shape.hidden, "top_k": TOP_K,
+                "contexts_per_gpu_per_step": args.batch, "tokens_per_gpu_per_step": total_tokens,
+                "mean_tokens_per_context": total_tokens / args.batch, "max_tokens": max_len,
+                "encoder": "all-MiniLM-L6-v2 shape (6 layers, hidden 384, 12 heads, ffn 1536), seeded random weights",
+                "parallelism": f"catalog row-sharded x{world}, queries data-parallel, RCCL all-gather x2" if world > 1 else "single GPU",
+            },
+            "p50_latency_ms_single_request": p50_ms,
+            "encode_ms_per_step": enc_ms, "search_ms_per_step": srch_ms, "search_kernel_ms": skern_ms,
+            "roofline": {
+                "kernel": "linear_kernel<128x128 tile, GELU> (FFN up-projection, fp32 MFMA 32x32x2)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "launches_timed": ffn_n, "avg_launch_ms": ffn_ms, "flops_per_launch": ffn_flops,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1 and args.workload == "49k7":
+            out["cpu_baseline"] = cpu_baseline(weights, shape, ids_h, cu_h, catalog, min(args.cpu_sample, args.batch))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,280 @@
+"""Drop-in serving objects: Recommender / MonitoredRecommender / EmbeddingIndex.
+
+Same constructor arguments, attributes, return types and error behaviour as the
+reference's src/inference/serve_recommendations.py (class Recommender :133-225,
+MonitoredRecommender :228-293, EmbeddingIndex :66-130, RecommendationMetrics :52-63),
+with the arithmetic moved onto the GPU behind libicrec's C ABI:
+
+    model.encode([query])        -> DeviceEncoder   (icrec_encode)
+    cos_sim + argsort + filter   -> DeviceIndex     (icrec_search)
+    model.encode(product_texts)  -> DeviceEncoder over the whole catalog at start-up
+
+`recommend_batch` is the one addition: many contexts in one GPU pass (what a
+micro-batching server calls); `recommend` is its single-query form.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import logging
+import os
+import time
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+from .encoder import DeviceEncoder
+from .model_io import LoadedModel, load_model_dir
+from .search import DeviceIndex
+
+logger = logging.getLogger(__name__)
+
+# on-disk cache names (reference: src/constants.py:88-92)
+INDEX_SUBDIR = ".embedding_index"
+MANIFEST_FILENAME = "manifest.json"
+EMBEDDINGS_FILENAME = "embeddings.npy"
+PRODUCT_IDS_FILENAME = "product_ids.json"
+
+
+@dataclass
+class RecommendationMetrics:
+    """Per-request metrics (same seven fields as the reference, :52-63)."""
+
+    user_id: str
+    query_embedding_time_ms: float
+    similarity_compute_time_ms: float
+    total_latency_ms: float
+    num_recommendations: int
+    top_score: float
+    avg_score: float
+    timestamp: float
+
+
+class EmbeddingIndex:
+    """On-disk cache of the [N, 384] fp32 product matrix, byte-compatible with the reference's
+    (:66-130): <corpus dir>/.embedding_index/<sha256("model_dir|corpus_path")[:16]>/
+    {manifest.json, embeddings.npy, product_ids.json}; valid only for the same corpus path,
+    model dir, corpus mtime and product-id list."""
+
+    def __init__(self, corpus_path: Path, model_dir: Path | str):
+        self.corpus_path = Path(corpus_path).resolve()
+        self.model_dir = model_dir
+        digest = hashlib.sha256(f"{self.model_dir!s}|{self.corpus_path!s}".encode()).hexdigest()
+        self._dir = self.corpus_path.parent / INDEX_SUBDIR / digest[:16]
+
+    @property
+    def directory(self) -> Path:
+        return self._dir
+
+    def _manifest_ok(self) -> bool:
+        try:
+            meta = json.loads((self._dir / MANIFEST_FILENAME).read_text())
+            return (meta.get("corpus_path") == str(self.corpus_path)
+                    and meta.get("model_dir") == str(self.model_dir)
+                    and meta.get("corpus_mtime") == self.corpus_path.stat().st_mtime)
+        except (OSError, ValueError):
+            return False
+
+    def load(self, product_ids: list[str]) -> Optional[np.ndarray]:
+        """Cached matrix, or None on any mismatch / missing file."""
+        if not self._manifest_ok():
+            return None
+        try:
+            emb = np.load(self._dir / EMBEDDINGS_FILENAME)  # allow_pickle stays False
+            cached_ids = json.loads((self._dir / PRODUCT_IDS_FILENAME).read_text())
+        except (OSError, ValueError):
+            return None
+        if cached_ids != product_ids or len(emb) != len(product_ids):
+            return None
+        return emb
+
+    def save(self, product_ids: list[str], embeddings: np.ndarray) -> None:
+        self._dir.mkdir(parents=True, exist_ok=True)
+        try:
+            mtime = self.corpus_path.stat().st_mtime
+        except OSError:
+            mtime = 0
+        (self._dir / MANIFEST_FILENAME).write_text(json.dumps({
+            "corpus_path": str(self.corpus_path), "model_dir": str(self.model_dir),
+            "corpus_mtime": mtime, "n_products": len(product_ids)}, indent=2))
+        np.save(self._dir / EMBEDDINGS_FILENAME, np.asarray(embeddings, dtype=np.float32))
+        (self._dir / PRODUCT_IDS_FILENAME).write_text(json.dumps(product_ids))
+        logger.info("Saved embedding index to %s (%d products)", self._dir, len(product_ids))
+
+
+class SbertModel:
+    """What `self.model` is in the reference (a SentenceTransformer): tokenizer + device encoder
+    with an `encode(texts, batch_size, show_progress_bar, normalize_embeddings)` method."""
+
+    def __init__(self, loaded: LoadedModel, device: torch.device):
+        self.tokenizer = loaded.tokenizer
+        self.max_seq_length = loaded.max_seq_length
+        self.shape = loaded.shape
+        self.device = device
+        self.encoder = DeviceEncoder(loaded.weights, loaded.shape, device)
+
+    def encode_to_device(self, texts: Sequence[str], tokens_per_call: int = 1 << 18) -> torch.Tensor:
+        """Embeddings [n, 384] left on the GPU (serving path: no host round trip)."""
+        return self.encoder.encode_ids(self.tokenizer(texts), max_tokens_per_call=tokens_per_call)
+
+    def encode(self, sentences, batch_size: int = 64, show_progress_bar: bool = False,
+               normalize_embeddings: bool = True, **_ignored) -> np.ndarray:
+        """SentenceTransformer.encode-compatible: numpy float32 [n, 384] (or [384] for a str).
+
+        The reference pads and runs `batch_size` texts per forward; packed varlen batching makes
+        the result independent of batch composition, so `batch_size` only bounds tokens per call."""
+        if not normalize_embeddings and self.shape.n_normalize > 1:
+            raise NotImplementedError("normalize_embeddings=False: construct the encoder with n_normalize-1")
+        single = isinstance(sentences, str)
+        texts = [sentences] if single else list(sentences)
+        if not texts:
+            return np.zeros((0, self.shape.hidden), np.float32)
+        emb = self.encode_to_device(texts, tokens_per_call=max(int(batch_size), 1) * 4096).cpu().numpy()
+        return emb[0] if single else emb
+
+
+class Recommender:
+    """Two-tower recommender: same surface as the reference's Recommender (:133-225)."""
+
+    def __init__(self, model_dir: Path | str, corpus_path: Path, batch_size: int = 64, use_index: bool = True):
+        self.model_dir = self._resolve_model_dir(model_dir)
+        self.corpus_path = Path(corpus_path).resolve()
+        self.product_ids, self.product_texts = self._load_corpus()
+        self.pid_to_text = dict(zip(self.product_ids, self.product_texts))
+        self._pid_to_row = {pid: i for i, pid in enumerate(self.product_ids)}
+        self.device = self._inference_device()
+        self.model = self._load_model()
+        self.product_embeddings = self._load_or_build_embeddings(batch_size, use_index)
+        self._index = DeviceIndex(self.product_embeddings, self.device)
+
+    # -- construction helpers (names follow the reference) ---------------------------------
+    def _resolve_model_dir(self, model_dir: Path | str) -> Path | str:
+        p = Path(model_dir)
+        return p.resolve() if p.exists() else model_dir
+
+    def _load_corpus(self) -> tuple[list[str], list[str]]:
+        """eval_corpus.json: {product_id: text}; key order = row order of the embedding matrix."""
+        with open(self.corpus_path) as f:
+            corpus = json.load(f)
+        ids = list(corpus.keys())
+        return ids, [corpus[pid] for pid in ids]
+
+    def _inference_device(self) -> torch.device:
+        """INFERENCE_DEVICE env ("cuda", "cuda:1") or the current HIP device.  This build has no
+        CPU/MPS path: anything else raises."""
+        override = os.getenv("INFERENCE_DEVICE")
+        name = override or "cuda"
+        dev = torch.device(name)
+        if dev.type != "cuda":
+            raise _native.IcrecError(f"INFERENCE_DEVICE={name!r}: this build runs on MI355X (cuda/HIP devices) only")
+        if not torch.cuda.is_available():
+            raise _native.IcrecError("no HIP device visible; the MI355X kernels have no CPU fallback")
+        return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+    def _load_model(self) -> SbertModel:
+        logger.info("Using inference device: %s", self.device)
+        return SbertModel(load_model_dir(self.model_dir), self.device)
+
+    def _load_or_build_embeddings(self, batch_size: int, use_index: bool) -> np.ndarray:
+        index = EmbeddingIndex(self.corpus_path, self.model_dir)
+        if use_index:
+            cached = index.load(self.product_ids)
+            if cached is not None:
+                logger.info("Loaded model from %s, corpus %d products (embeddings from index)", self.model_dir,
+                            len(self.product_ids))
+                return cached
+        embeddings = self.model.encode(self.product_texts, batch_size=batch_size, show_progress_bar=True,
+                                       normalize_embeddings=True)
+        if use_index:
+            index.save(self.product_ids, embeddings)
+        logger.info("Loaded model from %s, corpus %d products", self.model_dir, len(self.product_ids))
+        return embeddings
+
+    # -- the hot path -------------------------------------------------------------------------
+    def _excluded_rows(self, exclude_product_ids) -> list[int]:
+        if not exclude_product_ids:
+            return []
+        return [self._pid_to_row[p] for p in exclude_product_ids if p in self._pid_to_row]
+
+    def _rank(self, query_emb: torch.Tensor, top_k: int, exclude_lists: Optional[list[list[int]]]):
+        k = min(int(top_k), _native.ICREC_MAX_K, len(self.product_ids))
+        if top_k > _native.ICREC_MAX_K:
+            raise ValueError(f"top_k={top_k} exceeds the kernel limit {_native.ICREC_MAX_K} "
+                             "(the API schema allows at most 100)")
+        idx, sc = self._index.search(query_emb, k, exclude_lists)
+        return idx.cpu().numpy(), sc.cpu().numpy()
+
+    def _to_results(self, idx_row: np.ndarray, sc_row: np.ndarray) -> list[tuple[str, float]]:
+        return [(self.product_ids[int(i)], float(s)) for i, s in zip(idx_row, sc_row) if i >= 0]
+
+    def recommend_batch(self, queries: Sequence[str], top_k: int = 10,
+                        exclude_product_ids: Optional[Sequence[Optional[set[str]]]] = None
+                        ) -> list[list[tuple[str, float]]]:
+        """Many contexts in one GPU pass; element i equals recommend(queries[i], ...)."""
+        if not queries:
+            return []
+        top_k = max(int(top_k), 1)  # the reference's loop appends before testing len >= top_k (:223-224)
+        ex = None
+        if exclude_product_ids is not None and any(exclude_product_ids):
+            ex = [self._excluded_rows(e) for e in exclude_product_ids]
+        emb = self.model.encode_to_device(list(queries))
+        idx, sc = self._rank(emb, top_k, ex)
+        return [self._to_results(idx[i], sc[i]) for i in range(len(queries))]
+
+    def recommend(self, query: str, top_k: int = 10,
+                  exclude_product_ids: set[str] | None = None) -> list[tuple[str, float]]:
+        """Top-k (product_id, score) by cosine similarity, best first (reference :206-225)."""
+        return self.recommend_batch([query], top_k, [exclude_product_ids])[0]
+
+
+class MonitoredRecommender(Recommender):
+    """Recommender with timing; sets last_metrics after each recommend() (reference :228-293).
+    Device time comes from HIP events on the launch stream, host tokenisation is added to the
+    embedding time (it is part of model.encode in the reference)."""
+
+    def __init__(self, *args, metrics_logger: Optional[logging.Logger] = None, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.metrics_logger = metrics_logger or logging.getLogger("recommender.metrics")
+        self.last_metrics: Optional[RecommendationMetrics] = None
+
+    def recommend(self, query: str, top_k: int = 10, user_id: Optional[str] = None,
+                  exclude_product_ids: set[str] | None = None) -> list[tuple[str, float]]:
+        start = time.time()
+        results: list[tuple[str, float]] = []
+        encode_ms = sim_ms = 0.0
+        top_k = max(int(top_k), 1)
+        if True:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            t_tok = time.time()
+            ids = self.model.tokenizer([query])
+            tok_ms = (time.time() - t_tok) * 1000
+            stream = torch.cuda.current_stream(self.device)
+            e0.record(stream)
+            emb = self.model.encoder.encode_ids(ids)
+            e1.record(stream)
+            ex = [self._excluded_rows(exclude_product_ids)] if exclude_product_ids else None
+            idx, sc = self._rank(emb, top_k, ex)  # .cpu() inside synchronises the stream
+            e2.record(stream)
+            e2.synchronize()
+            encode_ms = tok_ms + e0.elapsed_time(e1)
+            sim_ms = e1.elapsed_time(e2)
+            results = self._to_results(idx[0], sc[0])
+        total_ms = (time.time() - start) * 1000
+        top_score = results[0][1] if results else 0.0
+        avg_score = sum(s for _, s in results) / len(results) if results else 0.0
+        self.last_metrics = RecommendationMetrics(
+            user_id=user_id or "anonymous", query_embedding_time_ms=encode_ms, similarity_compute_time_ms=sim_ms,
+            total_latency_ms=total_ms, num_recommendations=len(results), top_score=top_score, avg_score=avg_score,
+            timestamp=time.time())
+        self._log_metrics(self.last_metrics)
+        return results
+
+    def _log_metrics(self, m: RecommendationMetrics) -> None:
+        self.metrics_logger.info("recommendation_served", extra={
+            "user_id": m.user_id, "latency_ms": m.total_latency_ms, "encode_time_ms": m.query_embedding_time_ms,
+            "similarity_time_ms": m.similarity_compute_time_ms, "num_results": m.num_recommendations,
+            "top_score": m.top_score, "avg_score": m.avg_score})
