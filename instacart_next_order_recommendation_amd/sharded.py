@@ -85,6 +85,6 @@ class ShardedSearch:
         keys = self.backend.search_partial(q_all, k, self._local_exclusions(exclude_global))
         if self.world == 1:
             return self.backend.merge(keys.unsqueeze(0), k)
-        gathered = torch.empty((self.world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
-        dist.all_gather_into_tensor(gathered, keys.contiguous(), group=self.group)
-        return self.backend.merge(gathered, k)
+        gathered = torch.empty((self.world * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)
+        dist.all_gather_into_tensor(gathered, keys.contiguous(), group=self.group)  # rank-major concatenation
+        return self.backend.merge(gathered.view(self.world, keys.shape[0], keys.shape[1]), k)

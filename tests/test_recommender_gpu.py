@@ -1,0 +1,116 @@
+"""End to end through the drop-in classes: text in, (product_id, score) out, against the
+oracle run on the same token ids; EmbeddingIndex build / reuse; MonitoredRecommender metrics."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    import torch
+
+    assert torch.cuda.is_available()
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.model_io import write_synthetic_model_dir
+
+    root = tmp_path_factory.mktemp("rec")
+    model_dir = write_synthetic_model_dir(root / "model", seed=1)
+    corpus = syn.synthetic_catalog(700)
+    corpus_path = root / "processed" / "eval_corpus.json"
+    corpus_path.parent.mkdir()
+    corpus_path.write_text(json.dumps(corpus))
+    return {"model_dir": model_dir, "corpus_path": corpus_path, "corpus": corpus,
+            "queries": syn.synthetic_user_contexts(6, seed=9)}
+
+
+def _oracle_pipeline(rec, queries, k, excl_pids):
+    """The reference's recommend() restated with the oracle on the recommender's own token ids."""
+    from oracle import oracle
+
+    shape = rec.model.shape
+    cfg = oracle.make_cfg(vocab_size=shape.vocab_size, n_normalize=shape.n_normalize)
+    from instacart_next_order_recommendation_amd.encoder import pack_token_ids
+    from instacart_next_order_recommendation_amd.model_io import load_model_dir
+
+    w = load_model_dir(rec.model_dir).weights
+    ids, cu, _ = pack_token_ids(rec.model.tokenizer(queries))
+    q_emb = oracle.encode(w, cfg, ids, cu)
+    pids, cu_p, _ = pack_token_ids(rec.model.tokenizer(rec.product_texts))
+    P = oracle.encode(w, cfg, pids, cu_p)
+    row = {p: i for i, p in enumerate(rec.product_ids)}
+    excl = [[row[p] for p in e if p in row] for e in excl_pids]
+    idx, sc = oracle.search(q_emb, P, k, excl)
+    return P, [[(rec.product_ids[i], float(s)) for i, s in zip(idx[j], sc[j]) if i >= 0] for j in range(len(queries))]
+
+
+def test_recommender_end_to_end(world):
+    from instacart_next_order_recommendation_amd.recommender import MonitoredRecommender, Recommender
+
+    rec = Recommender(world["model_dir"], world["corpus_path"])
+    assert rec.product_ids == list(world["corpus"].keys())
+    assert rec.pid_to_text["1"] == world["corpus"]["1"]
+    assert rec.product_embeddings.shape == (700, 384) and rec.product_embeddings.dtype == np.float32
+    excl = [set(), {"1", "2"}, None, {"no-such-id"}, set(rec.product_ids[:50]), set()]
+    P, want = _oracle_pipeline(rec, world["queries"], 10, [e or set() for e in excl])
+    assert np.abs(rec.product_embeddings - P).max() < 5e-6  # catalog encode (index build) parity
+    for i, q in enumerate(world["queries"]):
+        got = rec.recommend(q, top_k=10, exclude_product_ids=excl[i])
+        assert isinstance(got, list) and all(isinstance(p, str) and isinstance(s, float) for p, s in got)
+        assert not {p for p, _ in got} & (excl[i] or set())
+        # embeddings differ from the oracle's by <= 5e-6, so ids agree except across near-ties
+        w = want[i]
+        for (gp, gs), (wp, ws) in zip(got, w):
+            assert abs(gs - ws) < 1e-4
+            if gp != wp:
+                j = [p for p, _ in w].index(gp) if gp in [p for p, _ in w] else None
+                assert j is not None and abs(w[j][1] - ws) < 2e-5, (i, gp, wp)
+    # batch form == single form, bit for bit
+    batch = rec.recommend_batch(world["queries"], 10, excl)
+    for i, q in enumerate(world["queries"]):
+        assert batch[i] == rec.recommend(q, 10, excl[i])
+    # fewer than top_k only when the catalog is exhausted
+    few = rec.recommend(world["queries"][0], top_k=100, exclude_product_ids=set(rec.product_ids[:650]))
+    assert len(few) == 50
+
+    # second construction reuses the on-disk EmbeddingIndex (same bits)
+    rec2 = MonitoredRecommender(world["model_dir"], world["corpus_path"])
+    np.testing.assert_array_equal(rec2.product_embeddings, rec.product_embeddings)
+    assert isinstance(rec2, Recommender)
+    out = rec2.recommend(world["queries"][2], top_k=5, user_id="u42", exclude_product_ids={"3"})
+    assert out == rec.recommend(world["queries"][2], 5, {"3"})
+    m = rec2.last_metrics
+    assert m.user_id == "u42" and m.num_recommendations == 5 and m.top_score == out[0][1]
+    assert abs(m.avg_score - sum(s for _, s in out) / 5) < 1e-12
+    assert 0 < m.query_embedding_time_ms and 0 < m.similarity_compute_time_ms and m.total_latency_ms >= m.similarity_compute_time_ms
+    assert rec2.recommend(world["queries"][2], 5)[0][1] >= 0 and rec2.last_metrics.user_id == "anonymous"
+
+
+def test_use_index_false_and_stale_cache(world, tmp_path):
+    from instacart_next_order_recommendation_amd.recommender import EmbeddingIndex, Recommender
+
+    corpus_path = tmp_path / "eval_corpus.json"
+    small = dict(list(world["corpus"].items())[:40])
+    corpus_path.write_text(json.dumps(small))
+    rec = Recommender(world["model_dir"], corpus_path, use_index=False)
+    assert not (tmp_path / ".embedding_index").exists()
+    # a cache written for a different id list is ignored and overwritten
+    EmbeddingIndex(corpus_path, rec.model_dir).save(["x"], np.zeros((1, 384), np.float32))
+    rec2 = Recommender(world["model_dir"], corpus_path)
+    np.testing.assert_array_equal(rec2.product_embeddings, rec.product_embeddings)
+    assert EmbeddingIndex(corpus_path, rec.model_dir).load(rec.product_ids) is not None
+
+
+def test_inference_device_env(world, monkeypatch):
+    from instacart_next_order_recommendation_amd._native import IcrecError
+    from instacart_next_order_recommendation_amd.recommender import Recommender
+
+    monkeypatch.setenv("INFERENCE_DEVICE", "cpu")
+    with pytest.raises(IcrecError):
+        Recommender(world["model_dir"], world["corpus_path"])
+    monkeypatch.setenv("INFERENCE_DEVICE", "cuda:0")
+    assert Recommender(world["model_dir"], world["corpus_path"]).device.index == 0
