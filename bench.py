@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="user contexts per GPU per step")
     ap.add_argument("--workload", default="49k7", choices=["49k7", "10m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-request (Q=1) latency loop")
     ap.add_argument("--cpu-sample", type=int, default=512, help="queries in the CPU baseline sample")
     return ap.parse_args()
 
@@ -150,7 +151,7 @@ def main() -> None:
 
     # ---- single-request latency (Q = 1, host-timed around the GPU call incl. the k*12-byte D2H)
     p50_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_latency:
         lat = []
         one_ids, one_cu = ids_d[: int(cu_h[1])], cu_d[:2]
         one_emb = torch.empty((1, shape.hidden), device=dev)

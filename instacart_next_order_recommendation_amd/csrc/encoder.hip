@@ -137,28 +137,32 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
 // and the softmax denominator is the sum of the two half-wave partial sums; the oracle
 // (icrec_oracle.c, attention block) accumulates in exactly this order.
 constexpr int DH = 32;
-constexpr int LDQ = 36;  // Q/K LDS row stride (even/odd split layout, like the GEMM tiles)
+constexpr int LDQ = 36;  // K LDS row stride (even/odd split layout, like the GEMM tiles)
 
-template <int NKT>  // max 32-key tiles per sequence in this launch (1, 2, 4, 8)
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                        int heads, int H, float scale, float* __restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) float smem_att[];
-    float* Ks = smem_att;                 // [NKT*32][LDQ]
-    float* Vs = Ks + NKT * 32 * LDQ;      // [NKT*32][32]
-    float* Qs = Vs + NKT * 32 * DH;       // [128][LDQ]
-    float* Ls = Qs + 128 * LDQ;           // [4][32] softmax denominators per wave
+// One launch per length bucket: NKT = max 32-key tiles (1, 2, 4, 8), WAVES = query blocks per
+// workgroup.  A workgroup whose sequence belongs to another bucket exits at once, so short
+// sequences run with the LDS footprint / occupancy of their own bucket even in a mixed batch.
+// K and V of the (sequence, head) live in LDS; each wave's 32 query rows come straight from
+// global memory into the B-operand registers.
+template <int NKT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attention_kernel(const float* __restrict__ qkv,
+                                                               const int32_t* __restrict__ cu, int heads, int H,
+                                                               float scale_log2e, float* __restrict__ ctx) {
+    __shared__ __attribute__((aligned(16))) float Ks[NKT * 32 * LDQ];
+    __shared__ __attribute__((aligned(16))) float Vs[NKT * 32 * DH];
+    __shared__ float Ls[WAVES * 32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int t0 = cu[s], L = cu[s + 1] - t0;
-    const int qb0 = blockIdx.y * 4;       // first query block of this workgroup
-    if (qb0 * 32 >= L) return;
     const int nkt = (L + 31) >> 5;
+    if (nkt > NKT || (NKT > 1 && nkt <= NKT / 2)) return;  // another bucket's sequence
+    const int qb0 = blockIdx.y * WAVES;
+    if (qb0 >= nkt) return;
     const int ld = 3 * H;
 
-    // stage K, V (all keys) and this workgroup's Q rows; rows past L are clamped to row L-1
-    // (their scores are masked to -inf / their outputs never stored).
-    for (int id = tid; id < nkt * 32 * 8; id += 256) {
+    // stage K (even/odd split) and V; rows past L are clamped (masked below / never stored)
+    for (int id = tid; id < nkt * 32 * 8; id += WAVES * 64) {
         const int row = id >> 3, c = id & 7;
         const int rr = row < L ? row : L - 1;
         const float* src = qkv + (size_t)(t0 + rr) * ld + hd * DH + c * 4;
@@ -169,26 +173,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         *reinterpret_cast<float2*>(kp + 4) = make_float2(kv.y, kv.w);
         *reinterpret_cast<float4*>(Vs + row * DH + c * 4) = vv;
     }
-    for (int id = tid; id < 128 * 8; id += 256) {
-        const int row = id >> 3, c = id & 7;
-        int rr = qb0 * 32 + row;
-        rr = rr < L ? rr : L - 1;
-        const float4 qv = *reinterpret_cast<const float4*>(qkv + (size_t)(t0 + rr) * ld + hd * DH + c * 4);
-        float* qp = Qs + row * LDQ + (c >> 1) * 8 + (c & 1) * 2;
-        *reinterpret_cast<float2*>(qp) = make_float2(qv.x, qv.z);
-        *reinterpret_cast<float2*>(qp + 4) = make_float2(qv.y, qv.w);
+    const int r = lane & 31, h = lane >> 5;
+    const int qb = qb0 + wave;
+    // this lane's query row -> B fragments (lane half h supplies the even / odd head dims)
+    float4 qf[4];
+    {
+        int qr = qb * 32 + r;
+        qr = qr < L ? qr : L - 1;
+        const float4* qp = reinterpret_cast<const float4*>(qkv + (size_t)(t0 + qr) * ld + hd * DH);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const float4 a = qp[2 * kq], b = qp[2 * kq + 1];
+            qf[kq] = h == 0 ? make_float4(a.x, a.z, b.x, b.z) : make_float4(a.y, a.w, b.y, b.w);
+        }
     }
     __syncthreads();
+    if (qb >= nkt) return;  // idle wave (no barrier below)
 
-    const int qb = qb0 + wave;
-    if (qb * 32 >= L) return;  // whole wave idle (no further barriers below)
-    const int r = lane & 31, h = lane >> 5;
-
-    // ---- S^T tiles: acc[kt][e] = sum_d K[kt*32+krow(e)][d] * Q[qb*32 + r][d]
+    // ---- S^T tiles: sc[kt][e] = sum_d K[kt*32 + krow(e)][d] * Q[qb*32 + r][d]
     f32x16 sc[NKT];
-    float4 qf[4];
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) qf[kq] = *reinterpret_cast<const float4*>(Qs + (wave * 32 + r) * LDQ + kq * 8 + h * 4);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -204,28 +207,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             }
         }
     }
-    // ---- scale, mask the key tail, row max (lane-local, then with the other half-wave)
+    // ---- scores in log2 units (scale * log2(e) folded), key tail masked, row max
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+            const bool last = kt == nkt - 1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + acc_row(e, lane);
-            const float v = key < L ? sc[kt][e] * scale : -INFINITY;
-            sc[kt][e] = v;
-            mx = fmaxf(mx, v);
+            for (int e = 0; e < 16; ++e) {
+                float v = sc[kt][e] * scale_log2e;
+                if (last && kt * 32 + acc_row(e, lane) >= L) v = -INFINITY;
+                sc[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
         }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // ---- exponentiate; denominator = this half-wave's keys ascending, then the two halves added
+    // ---- p = 2^(v - max); denominator = this half-wave's keys ascending, then the two halves added
     float lsum = 0.0f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = (kt < nkt) ? expf(sc[kt][e] - mx) : 0.0f;
-            sc[kt][e] = p;
-            if (kt < nkt) lsum = lsum + p;
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
+                sc[kt][e] = p;
+                lsum = lsum + p;
+            }
         }
+    }
     {
         const float other = __shfl_xor(lsum, 32, 64);
         lsum = h == 0 ? lsum + other : other + lsum;  // l0 + l1 in both halves
@@ -241,13 +251,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float vv = Vs[key * DH + r];
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], vv, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[kt][e], Vs[key * DH + r], o, 0, 0, 0);
             }
         }
     }
-    // ---- normalise rows by their denominator and store (row = query, column = head dim)
-    // (Ls was written by this wave's own lanes; wave-local LDS ordering makes it visible.)
+    // ---- normalise rows by their denominator and store (row = query, column = head dim);
+    // Ls was written by this wave's own lanes (wave-local LDS ordering makes it visible).
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int qrow = acc_row(e, lane);
@@ -337,21 +346,22 @@ static void launch_linear(const float* A, int M, int K, const float* W, int N, c
                        bias, out, nt);
 }
 
-template <int NKT>
-static int launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
-                            float* ctx, hipStream_t st) {
-    const size_t smem = (size_t)(NKT * 32 * LDQ + NKT * 32 * DH + 128 * LDQ + 128) * sizeof(float);
-    auto kern = attention_kernel<NKT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024));
-        attr_set = true;
-    }
-    const int qgroups = (max_seqlen + 127) / 128;
-    hipLaunchKernelGGL(kern, dim3(n_seqs * heads, qgroups), dim3(256), smem, st, qkv, cu, heads, H,
-                       1.0f / sqrtf((float)DH), ctx);
-    return ICREC_OK;
+// Launch every length bucket that can occur for max_seqlen (a bucket whose workgroups all exit
+// costs a few microseconds; single-sequence calls launch exactly one bucket).
+static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
+                             float* ctx, hipStream_t st) {
+    const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
+    const int nkt_max = (max_seqlen + 31) / 32;
+    const bool single = n_seqs == 1;
+    const dim3 grid1(n_seqs * heads, 1), grid2(n_seqs * heads, 2);
+    if (single ? nkt_max == 1 : true)
+        hipLaunchKernelGGL((attention_kernel<1, 1>), grid1, dim3(64), 0, st, qkv, cu, heads, H, sl2e, ctx);
+    if (single ? nkt_max == 2 : nkt_max >= 2)
+        hipLaunchKernelGGL((attention_kernel<2, 2>), grid1, dim3(128), 0, st, qkv, cu, heads, H, sl2e, ctx);
+    if (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)
+        hipLaunchKernelGGL((attention_kernel<4, 4>), grid1, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx);
+    if (nkt_max >= 5)
+        hipLaunchKernelGGL((attention_kernel<8, 4>), grid2, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx);
 }
 
 }  // namespace icrec
@@ -463,12 +473,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& L = e->layers[l];
         launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
-        int rc;
-        if (max_seqlen <= 32) rc = launch_attention<1>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
-        else if (max_seqlen <= 64) rc = launch_attention<2>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
-        else if (max_seqlen <= 128) rc = launch_attention<4>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
-        else rc = launch_attention<8>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
-        if (rc != ICREC_OK) return rc;
+        launch_attention(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
         launch_linear<false>(ctx, T, H, L.Wo, H, L.bo, t1, st);
         hipLaunchKernelGGL(add_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n, c.ln_eps);
         {
