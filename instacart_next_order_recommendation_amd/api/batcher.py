@@ -1,0 +1,104 @@
+"""Micro-batching in front of the recommender.
+
+The reference calls the blocking recommend() inside an `async def` endpoint
+(src/api/routes/recommend.py:89,139-151): one request in flight per process.  Here concurrent
+requests are coalesced: the first request of a batch waits at most `max_wait_ms` for company
+(or until `max_batch` are queued), then ONE recommend_batch() GPU pass runs in a worker thread
+and every caller gets its own slice.  Results are identical to per-request recommend() calls
+because packed varlen encoding and per-query top-k are batch-invariant.
+"""
+from __future__ import annotations
+
+import asyncio
+import time
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import Optional
+
+
+@dataclass
+class BatchTimings:
+    batch_size: int
+    encode_ms: float
+    search_ms: float
+    total_ms: float
+
+
+@dataclass
+class _Pending:
+    query: str
+    top_k: int
+    exclude: Optional[set]
+    future: asyncio.Future
+
+
+class MicroBatcher:
+    def __init__(self, recommender, max_batch: int = 256, max_wait_ms: float = 2.0):
+        self.recommender = recommender
+        self.max_batch = int(max_batch)
+        self.max_wait = float(max_wait_ms) / 1000.0
+        self._queue: Optional[asyncio.Queue] = None
+        self._task: Optional[asyncio.Task] = None
+        self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="icrec-gpu")  # one GPU stream
+
+    async def start(self) -> None:
+        if self._task is None:
+            self._queue = asyncio.Queue()
+            self._task = asyncio.create_task(self._run())
+
+    async def stop(self) -> None:
+        if self._task is not None:
+            self._task.cancel()
+            try:
+                await self._task
+            except asyncio.CancelledError:
+                pass
+            self._task = None
+        self._pool.shutdown(wait=False)
+
+    async def submit(self, query: str, top_k: int, exclude: Optional[set]):
+        """-> (results, BatchTimings) for this request."""
+        if self._task is None:
+            await self.start()
+        fut = asyncio.get_running_loop().create_future()
+        await self._queue.put(_Pending(query, top_k, exclude, fut))
+        return await fut
+
+    def _execute(self, batch: list[_Pending]):
+        t0 = time.perf_counter()
+        k = max(p.top_k for p in batch)
+        excl = [p.exclude for p in batch]
+        rec = self.recommender
+        if hasattr(rec, "recommend_batch_timed"):
+            results, enc_ms, srch_ms = rec.recommend_batch_timed([p.query for p in batch], k, excl)
+        else:
+            results, enc_ms, srch_ms = rec.recommend_batch([p.query for p in batch], k, excl), 0.0, 0.0
+        tm = BatchTimings(len(batch), enc_ms, srch_ms, (time.perf_counter() - t0) * 1000)
+        return [r[: p.top_k] for r, p in zip(results, batch)], tm
+
+    async def _run(self) -> None:
+        loop = asyncio.get_running_loop()
+        while True:
+            first = await self._queue.get()
+            batch = [first]
+            deadline = loop.time() + self.max_wait
+            while len(batch) < self.max_batch:
+                timeout = deadline - loop.time()
+                if timeout <= 0:
+                    # drain whatever is already queued without waiting
+                    while len(batch) < self.max_batch and not self._queue.empty():
+                        batch.append(self._queue.get_nowait())
+                    break
+                try:
+                    batch.append(await asyncio.wait_for(self._queue.get(), timeout))
+                except asyncio.TimeoutError:
+                    break
+            try:
+                results, tm = await loop.run_in_executor(self._pool, self._execute, batch)
+                for p, r in zip(batch, results):
+                    if not p.future.done():
+                        p.future.set_result((r, tm))
+            except Exception as exc:  # noqa: BLE001 - every waiter must see the failure
+                for p in batch:
+                    if not p.future.done():
+                        p.future.set_exception(exc)

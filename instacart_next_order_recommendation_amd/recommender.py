@@ -225,6 +225,29 @@ class Recommender:
         idx, sc = self._rank(emb, top_k, ex)
         return [self._to_results(idx[i], sc[i]) for i in range(len(queries))]
 
+    def recommend_batch_timed(self, queries: Sequence[str], top_k: int = 10, exclude_product_ids=None):
+        """recommend_batch plus (embedding ms incl. host tokenisation, similarity ms) from HIP events
+        on the launch stream — what the micro-batching server reports as per-request stats."""
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        top_k = max(int(top_k), 1)
+        ex = None
+        if exclude_product_ids is not None and any(exclude_product_ids):
+            ex = [self._excluded_rows(e) for e in exclude_product_ids]
+        t0 = time.time()
+        ids = self.model.tokenizer(list(queries))
+        tok_ms = (time.time() - t0) * 1000
+        stream = torch.cuda.current_stream(self.device)
+        e0.record(stream)
+        emb = self.model.encoder.encode_ids(ids)
+        e1.record(stream)
+        if top_k > _native.ICREC_MAX_K:
+            raise ValueError(f"top_k={top_k} exceeds the kernel limit {_native.ICREC_MAX_K}")
+        idx_d, sc_d = self._index.search(emb, min(top_k, len(self.product_ids)), ex)
+        e2.record(stream)
+        idx, sc = idx_d.cpu().numpy(), sc_d.cpu().numpy()
+        return ([self._to_results(idx[i], sc[i]) for i in range(len(queries))],
+                tok_ms + e0.elapsed_time(e1), e1.elapsed_time(e2))
+
     def recommend(self, query: str, top_k: int = 10,
                   exclude_product_ids: set[str] | None = None) -> list[tuple[str, float]]:
         """Top-k (product_id, score) by cosine similarity, best first (reference :206-225)."""
