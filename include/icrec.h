@@ -73,7 +73,15 @@ typedef struct icrec_bert_cfg {
     int32_t n_normalize;   /* how many times x / max(|x|_2, 1e-12) is applied
                               after pooling: 1 for the ST `Normalize` module,
                               +1 for encode(normalize_embeddings=True)       */
+    int32_t gemm_mode;     /* ICREC_GEMM_F32: every linear layer on the exact
+                              f32 MFMA (bit-identical to the oracle's fmaf
+                              chains); ICREC_GEMM_F16X3: linear layers on the
+                              f16 MFMA with 3-term operand splitting (fp32-level
+                              accuracy, ~2^-21 relative per product; csrc/gemm_x3.h) */
 } icrec_bert_cfg;
+
+#define ICREC_GEMM_F32 0
+#define ICREC_GEMM_F16X3 1
 
 /* Number of fp32 elements the weight blob must hold for `cfg`.
  * Blob layout (all fp32, row-major, HF `nn.Linear` weights are [out,in]):

@@ -14,6 +14,8 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libicrec.so"
 
 ICREC_MAX_K = 128
+GEMM_F32, GEMM_F16X3 = 0, 1
+GEMM_MODES = {"f32": GEMM_F32, "f16x3": GEMM_F16X3}
 
 #: every symbol include/icrec.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -38,6 +40,7 @@ class BertCfg(C.Structure):
         ("vocab_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32),
         ("heads", C.c_int32), ("intermediate", C.c_int32), ("max_position", C.c_int32),
         ("type_vocab", C.c_int32), ("ln_eps", C.c_float), ("n_normalize", C.c_int32),
+        ("gemm_mode", C.c_int32),
     ]
 
 

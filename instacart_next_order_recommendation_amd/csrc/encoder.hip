@@ -8,6 +8,7 @@
 // Arithmetic follows transformers/models/bert/modeling_bert.py (tf:) as cited per kernel,
 // and oracle/icrec_oracle.c reduction orders where a kernel says "oracle order".
 #include "common.h"
+#include "gemm_x3.h"
 
 namespace icrec {
 
@@ -22,9 +23,11 @@ __device__ __forceinline__ int find_seq(const int32_t* __restrict__ cu, int n_se
 }
 
 // LayerNorm of one 384-wide row held 6 values per lane (element i = lane + 64*j); oracle order.
-template <int H>
+// SPLIT additionally writes the row as f16 hi/lo planes for the f16x3 GEMMs (gemm_x3.h).
+template <int H, bool SPLIT>
 __device__ __forceinline__ void ln_row(float (&v)[H / 64], const float* __restrict__ g, const float* __restrict__ b,
-                                       float eps, float* __restrict__ out, int lane) {
+                                       float eps, float* __restrict__ out, _Float16* __restrict__ oh,
+                                       _Float16* __restrict__ ol, int lane) {
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < H / 64; ++j) s = s + v[j];
@@ -40,18 +43,26 @@ __device__ __forceinline__ void ln_row(float (&v)[H / 64], const float* __restri
 #pragma unroll
     for (int j = 0; j < H / 64; ++j) {
         const int i = lane + 64 * j;
-        out[i] = fmaf((v[j] - mean) * rstd, g[i], b[i]);
+        const float y = fmaf((v[j] - mean) * rstd, g[i], b[i]);
+        out[i] = y;
+        if (SPLIT) {
+            _Float16 hi, lo;
+            split_f16(y, hi, lo);
+            oh[i] = hi;
+            ol[i] = lo;
+        }
     }
 }
 
 // ---------------------------------------------------------------- K1: embeddings + LN (tf:98-107)
-template <int H>
+template <int H, bool SPLIT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids,
                                                        const int32_t* __restrict__ cu, int n_seqs, int T,
                                                        const float* __restrict__ word, const float* __restrict__ pos,
                                                        const float* __restrict__ type, const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, int vocab, int max_pos,
-                                                       float* __restrict__ x) {
+                                                       float* __restrict__ x, _Float16* __restrict__ xh,
+                                                       _Float16* __restrict__ xl) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -66,15 +77,16 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
         const int i = lane + 64 * j;
         v[j] = (word[(size_t)id * H + i] + type[i]) + pos[(size_t)p * H + i];
     }
-    ln_row<H>(v, g, b, eps, x + (size_t)t * H, lane);
+    ln_row<H, SPLIT>(v, g, b, eps, x + (size_t)t * H, xh + (size_t)t * H, xl + (size_t)t * H, lane);
 }
 
 // ---------------------------------------------------------------- residual + LN (tf:292, tf:350)
 // x <- LN(a + x); `a` already holds dense(.) + bias.
-template <int H>
+template <int H, bool SPLIT>
 __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a, float* __restrict__ x, int T,
                                                      const float* __restrict__ g, const float* __restrict__ b,
-                                                     float eps) {
+                                                     float eps, _Float16* __restrict__ xh,
+                                                     _Float16* __restrict__ xl) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
         const int i = lane + 64 * j;
         v[j] = a[(size_t)t * H + i] + x[(size_t)t * H + i];
     }
-    ln_row<H>(v, g, b, eps, x + (size_t)t * H, lane);
+    ln_row<H, SPLIT>(v, g, b, eps, x + (size_t)t * H, xh + (size_t)t * H, xl + (size_t)t * H, lane);
 }
 
 // ---------------------------------------------------------------- GEMM: out = A . W^T + bias [, GELU]
@@ -126,6 +138,58 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
     }
 }
 
+// Same layers on the f16 matrix cores with 3-term operand splitting (gemm_x3.h).  A and W arrive as
+// f16 hi/lo planes.  EPI 0: out_f32 = acc + bias.  EPI 1: erf-GELU, result written as hi/lo planes
+// (the FFN-down GEMM's A operand) and never as fp32.
+template <class Cfg, int EPI>
+__global__ __launch_bounds__(Cfg::THREADS) void linear_x3_kernel(
+    const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int M, int K, const _Float16* __restrict__ Wh,
+    const _Float16* __restrict__ Wl, int N, const float* __restrict__ bias, float* __restrict__ out,
+    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int n_tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_tiles_n, nt = bid % n_tiles_n;
+    const int64_t m0 = (int64_t)mt * Cfg::BM, n0 = (int64_t)nt * Cfg::BN;
+    f32x16 acc0[Cfg::TM][Cfg::TN], acc1[Cfg::TM][Cfg::TN];
+    tile_gemm_h<Cfg>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+        const int64_t col = n0 + (wn * Cfg::TN + j) * 32 + (lane & 31);
+        const float bv = col < N ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
+                if (row < M && col < N) {
+                    float v = fmaf(acc1[i][j][e], LO_UNSCALE, acc0[i][j][e]) + bv;
+                    if (EPI == 1) {
+                        v = gelu_erf(v);
+                        _Float16 hi, lo;
+                        split_f16(v, hi, lo);
+                        oh[row * N + col] = hi;
+                        ol[row * N + col] = lo;
+                    } else {
+                        out[row * N + col] = v;
+                    }
+                }
+            }
+    }
+}
+
+// W (fp32) -> f16 hi/lo planes, once at encoder creation.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, size_t n,
+                                                           _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        _Float16 a, b;
+        split_f16(w[i], a, b);
+        hi[i] = a;
+        lo[i] = b;
+    }
+}
+
 // ---------------------------------------------------------------- attention (tf:111-136, 164-203)
 // One workgroup = one (sequence, head) and up to four 32-row query blocks (one per wave).
 // S^T = K.Q^T is computed with keys on the accumulator rows, so each lane ends up with the
@@ -144,10 +208,11 @@ constexpr int LDQ = 36;  // K LDS row stride (even/odd split layout, like the GE
 // sequences run with the LDS footprint / occupancy of their own bucket even in a mixed batch.
 // K and V of the (sequence, head) live in LDS; each wave's 32 query rows come straight from
 // global memory into the B-operand registers.
-template <int NKT, int WAVES>
+template <int NKT, int WAVES, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void attention_kernel(const float* __restrict__ qkv,
                                                                const int32_t* __restrict__ cu, int heads, int H,
-                                                               float scale_log2e, float* __restrict__ ctx) {
+                                                               float scale_log2e, float* __restrict__ ctx,
+                                                               _Float16* __restrict__ ch, _Float16* __restrict__ cl) {
     __shared__ __attribute__((aligned(16))) float Ks[NKT * 32 * LDQ];
     __shared__ __attribute__((aligned(16))) float Vs[NKT * 32 * DH];
     __shared__ float Ls[WAVES * 32];
@@ -261,7 +326,18 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(const float* __re
     for (int e = 0; e < 16; ++e) {
         const int qrow = acc_row(e, lane);
         const int tq = qb * 32 + qrow;
-        if (tq < L) ctx[(size_t)(t0 + tq) * H + hd * DH + r] = o[e] / Ls[wave * 32 + qrow];
+        if (tq < L) {
+            const float v = o[e] / Ls[wave * 32 + qrow];
+            const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
+            if (SPLIT) {
+                _Float16 hi, lo;
+                split_f16(v, hi, lo);
+                ch[at] = hi;
+                cl[at] = lo;
+            } else {
+                ctx[at] = v;
+            }
+        }
     }
 }
 
@@ -303,12 +379,15 @@ constexpr int HID = 384;
 
 struct LayerW {
     float *Wqkv, *bqkv, *Wo, *bo, *g1, *b1n, *W1, *b1, *W2, *b2, *g2, *b2n;
+    // f16 hi/lo planes of the four weight matrices (gemm_mode F16X3 only)
+    _Float16 *Wqkv_h, *Wqkv_l, *Wo_h, *Wo_l, *W1_h, *W1_l, *W2_h, *W2_l;
 };
 struct Encoder {
     icrec_bert_cfg cfg;
     int device = 0;
-    float* blob = nullptr;   // the uploaded weight blob
-    float* extra = nullptr;  // repacked Wqkv / bqkv
+    float* blob = nullptr;      // the uploaded weight blob
+    float* extra = nullptr;     // repacked Wqkv / bqkv
+    _Float16* planes = nullptr; // split weight planes (F16X3)
     float *word, *pos, *type, *eg, *eb;
     LayerW layers[64];
 };
@@ -321,22 +400,24 @@ static size_t weight_count(const icrec_bert_cfg* c) {
 }
 
 struct EncWs {
-    size_t x, qkv, ctx, t1, h, total;
+    size_t x, xs, qkv, ctx, t1, h, total;
 };
 static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     EncWs w;
     size_t o = 0;
     w.x = o;   o += al((size_t)T * c.hidden * 4);
+    w.xs = o;  o += al((size_t)T * c.hidden * 4);        // x as f16 hi/lo planes (F16X3)
     w.qkv = o; o += al((size_t)T * 3 * c.hidden * 4);
-    w.ctx = o; o += al((size_t)T * c.hidden * 4);
+    w.ctx = o; o += al((size_t)T * c.hidden * 4);        // fp32 ctx, or its two f16 planes
     w.t1 = o;  o += al((size_t)T * c.hidden * 4);
-    w.h = o;   o += al((size_t)T * c.intermediate * 4);
+    w.h = o;   o += al((size_t)T * c.intermediate * 4);  // fp32 h, or its two f16 planes
     w.total = o;
     return w;
 }
 
 typedef TileCfg<2, 2, 2, 2> GemmBig;  // 128 x 128 output tile, 4 waves
+typedef TileCfg<2, 4, 2, 1> GemmX3;   // 128 x 128 output tile, 8 waves of 64 x 32 (two accumulator sets per tile)
 
 template <bool GELU>
 static void launch_linear(const float* A, int M, int K, const float* W, int N, const float* bias, float* out,
@@ -346,22 +427,40 @@ static void launch_linear(const float* A, int M, int K, const float* W, int N, c
                        bias, out, nt);
 }
 
+template <int EPI>
+static int launch_linear_x3(const _Float16* Ah, const _Float16* Al, int M, int K, const _Float16* Wh,
+                            const _Float16* Wl, int N, const float* bias, float* out, _Float16* oh, _Float16* ol,
+                            hipStream_t st) {
+    auto kern = linear_x3_kernel<GemmX3, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)SmemH<GemmX3>::BYTES));
+        attr_set = true;
+    }
+    const int mt = (M + GemmX3::BM - 1) / GemmX3::BM, nt = (N + GemmX3::BN - 1) / GemmX3::BN;
+    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(GemmX3::THREADS), SmemH<GemmX3>::BYTES, st, Ah, Al, M, K, Wh, Wl, N,
+                       bias, out, oh, ol, nt);
+    return ICREC_OK;
+}
+
 // Launch every length bucket that can occur for max_seqlen (a bucket whose workgroups all exit
 // costs a few microseconds; single-sequence calls launch exactly one bucket).
+template <bool SPLIT>
 static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
-                             float* ctx, hipStream_t st) {
+                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st) {
     const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
     const int nkt_max = (max_seqlen + 31) / 32;
     const bool single = n_seqs == 1;
     const dim3 grid1(n_seqs * heads, 1), grid2(n_seqs * heads, 2);
     if (single ? nkt_max == 1 : true)
-        hipLaunchKernelGGL((attention_kernel<1, 1>), grid1, dim3(64), 0, st, qkv, cu, heads, H, sl2e, ctx);
+        hipLaunchKernelGGL((attention_kernel<1, 1, SPLIT>), grid1, dim3(64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
     if (single ? nkt_max == 2 : nkt_max >= 2)
-        hipLaunchKernelGGL((attention_kernel<2, 2>), grid1, dim3(128), 0, st, qkv, cu, heads, H, sl2e, ctx);
+        hipLaunchKernelGGL((attention_kernel<2, 2, SPLIT>), grid1, dim3(128), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
     if (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)
-        hipLaunchKernelGGL((attention_kernel<4, 4>), grid1, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx);
+        hipLaunchKernelGGL((attention_kernel<4, 4, SPLIT>), grid1, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
     if (nkt_max >= 5)
-        hipLaunchKernelGGL((attention_kernel<8, 4>), grid2, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx);
+        hipLaunchKernelGGL((attention_kernel<8, 4, SPLIT>), grid2, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
 }
 
 }  // namespace icrec
@@ -377,10 +476,11 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     ICREC_REQUIRE(weights_host && cfg && out, "icrec_encoder_create: NULL argument");
     ICREC_REQUIRE(cfg->hidden == HID, "icrec_encoder_create: this build supports hidden=384 only (got %d)", cfg->hidden);
     ICREC_REQUIRE(cfg->heads * DH == cfg->hidden, "icrec_encoder_create: head_dim must be 32 (heads=%d)", cfg->heads);
-    ICREC_REQUIRE(cfg->intermediate >= 128 && cfg->intermediate % BK == 0, "icrec_encoder_create: bad intermediate size %d", cfg->intermediate);
+    ICREC_REQUIRE(cfg->intermediate >= 128 && cfg->intermediate % HBK == 0, "icrec_encoder_create: bad intermediate size %d", cfg->intermediate);
     ICREC_REQUIRE(cfg->layers >= 1 && cfg->layers <= 64, "icrec_encoder_create: layers must be in [1,64]");
     ICREC_REQUIRE(cfg->vocab_size >= 1 && cfg->max_position >= 1 && cfg->type_vocab >= 1, "icrec_encoder_create: bad vocab/position sizes");
     ICREC_REQUIRE(cfg->n_normalize >= 0 && cfg->n_normalize <= 4, "icrec_encoder_create: n_normalize must be in [0,4]");
+    ICREC_REQUIRE(cfg->gemm_mode == ICREC_GEMM_F32 || cfg->gemm_mode == ICREC_GEMM_F16X3, "icrec_encoder_create: unknown gemm_mode %d", cfg->gemm_mode);
     ICREC_REQUIRE(n_floats == weight_count(cfg), "icrec_encoder_create: weight blob has %zu floats, expected %zu", n_floats, weight_count(cfg));
     ICREC_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -393,10 +493,14 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     e->cfg = *cfg;
     e->device = device;
     const size_t H = cfg->hidden, I = cfg->intermediate;
+    const size_t mat_per_layer = 3 * H * H + H * H + I * H + H * I;
+    const bool x3 = cfg->gemm_mode == ICREC_GEMM_F16X3;
     if (hipMalloc(&e->blob, n_floats * 4) != hipSuccess ||
-        hipMalloc(&e->extra, (size_t)cfg->layers * (3 * H * H + 3 * H) * 4) != hipSuccess) {
+        hipMalloc(&e->extra, (size_t)cfg->layers * (3 * H * H + 3 * H) * 4) != hipSuccess ||
+        (x3 && hipMalloc(&e->planes, (size_t)cfg->layers * mat_per_layer * 2 * sizeof(_Float16)) != hipSuccess)) {
         set_error("icrec_encoder_create: hipMalloc failed");
         if (e->blob) (void)hipFree(e->blob);
+        if (e->extra) (void)hipFree(e->extra);
         delete e;
         return ICREC_ENOMEM;
     }
@@ -408,6 +512,12 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     e->eg = p;   p += H;
     e->eb = p;   p += H;
     float* x = e->extra;
+    _Float16* pl = e->planes;
+    auto split = [&](const float* w, size_t n, _Float16*& hi, _Float16*& lo) {
+        hi = pl; pl += n;
+        lo = pl; pl += n;
+        hipLaunchKernelGGL(split_planes_kernel, dim3(1024), dim3(256), 0, 0, w, n, hi, lo);
+    };
     for (int l = 0; l < cfg->layers; ++l) {
         LayerW& L = e->layers[l];
         L.Wqkv = x; x += 3 * H * H;
@@ -421,7 +531,14 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
         L.W1 = p; p += I * H; L.b1 = p; p += I;
         L.W2 = p; p += H * I; L.b2 = p; p += H;
         L.g2 = p; p += H; L.b2n = p; p += H;
+        if (x3) {
+            split(L.Wqkv, 3 * H * H, L.Wqkv_h, L.Wqkv_l);
+            split(L.Wo, H * H, L.Wo_h, L.Wo_l);
+            split(L.W1, I * H, L.W1_h, L.W1_l);
+            split(L.W2, H * I, L.W2_h, L.W2_l);
+        }
     }
+    ICREC_HIP(hipGetLastError());
     ICREC_HIP(hipDeviceSynchronize());
     *out = reinterpret_cast<icrec_encoder*>(e);
     return ICREC_OK;
@@ -433,6 +550,7 @@ int icrec_encoder_destroy(icrec_encoder* h) {
     (void)hipSetDevice(e->device);
     (void)hipFree(e->blob);
     (void)hipFree(e->extra);
+    if (e->planes) (void)hipFree(e->planes);
     delete e;
     return ICREC_OK;
 }
@@ -467,21 +585,52 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const icrec_bert_cfg& c = e->cfg;
     const int H = c.hidden, I = c.intermediate;
     const int rows_grid = (T + 3) / 4;
+    const bool x3 = c.gemm_mode == ICREC_GEMM_F16X3;
+    // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
+    _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
+    _Float16* xl = xh + (size_t)T * H;
+    _Float16* ch = reinterpret_cast<_Float16*>(ctx);
+    _Float16* cl = ch + (size_t)T * H;
+    _Float16* hh = reinterpret_cast<_Float16*>(hb);
+    _Float16* hl = hh + (size_t)T * I;
 
-    hipLaunchKernelGGL(embed_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T, e->word,
-                       e->pos, e->type, e->eg, e->eb, c.ln_eps, c.vocab_size, c.max_position, x);
+    if (x3)
+        hipLaunchKernelGGL((embed_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T,
+                           e->word, e->pos, e->type, e->eg, e->eb, c.ln_eps, c.vocab_size, c.max_position, x, xh, xl);
+    else
+        hipLaunchKernelGGL((embed_ln_kernel<HID, false>), dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T,
+                           e->word, e->pos, e->type, e->eg, e->eb, c.ln_eps, c.vocab_size, c.max_position, x, xh, xl);
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& L = e->layers[l];
-        launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
-        launch_attention(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, st);
-        launch_linear<false>(ctx, T, H, L.Wo, H, L.bo, t1, st);
-        hipLaunchKernelGGL(add_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n, c.ln_eps);
-        {
-            ScopedTimer tm(T_FFN_UP, st);
-            launch_linear<true>(x, T, H, L.W1, I, L.b1, hb, st);
+        if (x3) {
+            int rc = launch_linear_x3<0>(xh, xl, T, H, L.Wqkv_h, L.Wqkv_l, 3 * H, L.bqkv, qkv, nullptr, nullptr, st);
+            if (rc != ICREC_OK) return rc;
+            launch_attention<true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            launch_linear_x3<0>(ch, cl, T, H, L.Wo_h, L.Wo_l, H, L.bo, t1, nullptr, nullptr, st);
+            hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
+                               c.ln_eps, xh, xl);
+            {
+                ScopedTimer tm(T_FFN_UP, st);
+                rc = launch_linear_x3<1>(xh, xl, T, H, L.W1_h, L.W1_l, I, L.b1, nullptr, hh, hl, st);
+            }
+            if (rc != ICREC_OK) return rc;
+            launch_linear_x3<0>(hh, hl, T, I, L.W2_h, L.W2_l, H, L.b2, t1, nullptr, nullptr, st);
+            hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n,
+                               c.ln_eps, xh, xl);
+        } else {
+            launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
+            launch_attention<false>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            launch_linear<false>(ctx, T, H, L.Wo, H, L.bo, t1, st);
+            hipLaunchKernelGGL((add_ln_kernel<HID, false>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
+                               c.ln_eps, xh, xl);
+            {
+                ScopedTimer tm(T_FFN_UP, st);
+                launch_linear<true>(x, T, H, L.W1, I, L.b1, hb, st);
+            }
+            launch_linear<false>(hb, T, I, L.W2, H, L.b2, t1, st);
+            hipLaunchKernelGGL((add_ln_kernel<HID, false>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n,
+                               c.ln_eps, xh, xl);
         }
-        launch_linear<false>(hb, T, I, L.W2, H, L.b2, t1, st);
-        hipLaunchKernelGGL(add_ln_kernel<HID>, dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n, c.ln_eps);
     }
     hipLaunchKernelGGL(pool_norm_kernel<HID>, dim3(n_seqs), dim3(HID), 0, st, x, cu_dev, c.n_normalize, out_dev);
     ICREC_HIP(hipGetLastError());

@@ -62,6 +62,7 @@ typedef struct {
     int32_t vocab_size, hidden, layers, heads, intermediate, max_position, type_vocab;
     float ln_eps;
     int32_t n_normalize;
+    int32_t gemm_mode; /* HIP engine option; unused here (the oracle is always exact fp32) */
 } oracle_bert_cfg; /* same layout as icrec_bert_cfg in include/icrec.h */
 
 /* ---------------------------------------------------------------- helpers */

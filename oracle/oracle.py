@@ -21,6 +21,7 @@ class BertCfg(C.Structure):
         ("vocab_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32),
         ("heads", C.c_int32), ("intermediate", C.c_int32), ("max_position", C.c_int32),
         ("type_vocab", C.c_int32), ("ln_eps", C.c_float), ("n_normalize", C.c_int32),
+        ("gemm_mode", C.c_int32),  # engine option of the HIP library; the oracle ignores it
     ]
 
 
@@ -78,7 +79,7 @@ def _i32(a) -> np.ndarray:
 def make_cfg(vocab_size=30522, hidden=384, layers=6, heads=12, intermediate=1536,
              max_position=512, type_vocab=2, ln_eps=1e-12, n_normalize=2) -> BertCfg:
     return BertCfg(vocab_size, hidden, layers, heads, intermediate, max_position, type_vocab,
-                   ln_eps, n_normalize)
+                   ln_eps, n_normalize, 0)
 
 
 def weight_count(cfg: BertCfg) -> int:

@@ -38,7 +38,7 @@ def test_struct_layout_matches_oracle(native):
 
     from oracle import oracle
 
-    assert C.sizeof(native.BertCfg) == C.sizeof(oracle.BertCfg) == 36
+    assert C.sizeof(native.BertCfg) == C.sizeof(oracle.BertCfg) == 40
     assert [f[0] for f in native.BertCfg._fields_] == [f[0] for f in oracle.BertCfg._fields_]
 
 
@@ -50,7 +50,7 @@ def test_weight_count_agrees(native):
 
     s = BertShape()
     cfg = native.BertCfg(s.vocab_size, s.hidden, s.layers, s.heads, s.intermediate, s.max_position, s.type_vocab,
-                         s.ln_eps, s.n_normalize)
+                         s.ln_eps, s.n_normalize, 0)
     assert native.lib().icrec_encoder_weight_count(C.byref(cfg)) == s.weight_count() == oracle.weight_count(oracle.make_cfg())
     assert s.weight_count() == 22_713_216 - (384 * 384 + 384)  # BertModel's 22.7M minus the unused pooler
 
