@@ -452,7 +452,7 @@ static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, in
     const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
     const int nkt_max = (max_seqlen + 31) / 32;
     const bool single = n_seqs == 1;
-    const dim3 grid1(n_seqs * heads, 1), grid2(n_seqs * heads, 2);
+    const dim3 grid1(n_seqs * heads, 1);
     if (single ? nkt_max == 1 : true)
         hipLaunchKernelGGL((attention_kernel<1, 1, SPLIT>), grid1, dim3(64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
     if (single ? nkt_max == 2 : nkt_max >= 2)
@@ -460,7 +460,7 @@ static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, in
     if (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)
         hipLaunchKernelGGL((attention_kernel<4, 4, SPLIT>), grid1, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
     if (nkt_max >= 5)
-        hipLaunchKernelGGL((attention_kernel<8, 4, SPLIT>), grid2, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
+        hipLaunchKernelGGL((attention_kernel<8, 8, SPLIT>), grid1, dim3(512), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
 }
 
 }  // namespace icrec
