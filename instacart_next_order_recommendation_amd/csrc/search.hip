@@ -35,14 +35,15 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- score + select
-constexpr int QCAP = 16;  // candidate queue slots per query between two list merges
+// candidate queue slots per query between two list merges (more when few queries share the LDS)
+template <class Cfg> struct QCap { static constexpr int V = Cfg::BN <= 32 ? 64 : 16; };
 
 template <class Cfg>
 struct SearchSmem {
     // dynamic LDS carve (all offsets multiples of 16 B)
     static __host__ __device__ size_t bytes(int k) {
         return (size_t)Cfg::LDS_FLOATS * 4 + (size_t)Cfg::BN * (8 /*thr*/ + 4 /*cnt*/) + 16 /*flags*/ +
-               (size_t)Cfg::BN * k * 8 + (size_t)Cfg::BN * QCAP * 8;
+               (size_t)Cfg::BN * k * 8 + (size_t)Cfg::BN * QCap<Cfg>::V * 8;
     }
 };
 
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     u64* list = reinterpret_cast<u64*>(flags + 4);
     u64* queue = list + (size_t)Cfg::BN * k;
 
+    constexpr int QCAP = QCap<Cfg>::V;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     const int chunk = bid / n_qtiles, qtile = bid % n_qtiles;
     const int q0 = qtile * Cfg::BN;
 
-    for (int i = tid; i < Cfg::BN; i += Cfg::THREADS) { thr[i] = 0ull; cnt[i] = 0; }
+    for (int i = tid; i < Cfg::BN; i += Cfg::THREADS) { thr[i] = (q0 + i < Q) ? 0ull : ~0ull; cnt[i] = 0; }
     for (int i = tid; i < Cfg::BN * k; i += Cfg::THREADS) list[i] = 0ull;
     if (tid < 4) flags[tid] = 0;
     __syncthreads();
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
         myq[j] = (wn * Cfg::TN + j) * 32 + (lane & 31);
-        mythr[j] = 0ull;
         const int gq = q0 + myq[j];
+        mythr[j] = gq < Q ? 0ull : ~0ull;  // padding columns never produce candidates
         ex_lo[j] = ex_hi[j] = 0;
         if (excl_off != nullptr && gq < Q) { ex_lo[j] = excl_off[gq]; ex_hi[j] = excl_off[gq + 1]; }
     }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
         unsigned long long pend = 0ull;
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
-            const float thr_s = mythr[j] ? key_score(mythr[j]) : -INFINITY;
+            const float thr_s = mythr[j] == ~0ull ? INFINITY : (mythr[j] ? key_score(mythr[j]) : -INFINITY);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -291,8 +293,8 @@ static Plan make_plan(const Index* ix, int Q, int k) {
     p.n_qtiles = (Q + p.BN - 1) / p.BN;
     p.Qpad = p.n_qtiles * p.BN;
     p.n_row_tiles = (int)((ix->n_rows + p.BM - 1) / p.BM);
-    // aim for ~3 resident blocks per CU over the whole grid, at most 256 chunks (merge_kernel limit)
-    int want_chunks = (3 * ix->n_cu + p.n_qtiles - 1) / p.n_qtiles;
+    // one full wave of resident blocks (2 per CU fit by LDS/VGPR), at most 256 chunks (merge_kernel limit)
+    int want_chunks = (2 * ix->n_cu) / p.n_qtiles;
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > 256) want_chunks = 256;
     if (want_chunks > p.n_row_tiles) want_chunks = p.n_row_tiles;
