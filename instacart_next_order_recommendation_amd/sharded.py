@@ -70,13 +70,20 @@ class ShardedSearch:
             return None
         return [[r - self.row_lo for r in e if self.row_lo <= r < self.row_hi] for e in exclude_global]
 
+    def _all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        """Rank-major concatenation of equally shaped [n, c] tensors.  With the gloo backend (CPU
+        rehearsals / tests) device tensors are staged through the host; nccl (= RCCL) gathers in HBM."""
+        out = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
-            return q_local
-        q_all = torch.empty((self.world * q_local.shape[0], q_local.shape[1]), dtype=q_local.dtype,
-                            device=q_local.device)
-        dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=self.group)
-        return q_all
+        return q_local if self.world == 1 else self._all_gather_rows(q_local)
 
     def search(self, q_local: torch.Tensor, k: int, exclude_global: Optional[Sequence[Iterable[int]]] = None):
         """q_local [Q/W, d] -> (idx int64 [Q, k] global rows, score float32 [Q, k]) on every rank.
@@ -85,6 +92,5 @@ class ShardedSearch:
         keys = self.backend.search_partial(q_all, k, self._local_exclusions(exclude_global))
         if self.world == 1:
             return self.backend.merge(keys.unsqueeze(0), k)
-        gathered = torch.empty((self.world * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)
-        dist.all_gather_into_tensor(gathered, keys.contiguous(), group=self.group)  # rank-major concatenation
+        gathered = self._all_gather_rows(keys)
         return self.backend.merge(gathered.view(self.world, keys.shape[0], keys.shape[1]), k)
