@@ -1,0 +1,112 @@
+"""Single-request fast path: icrec_encode + icrec_search replayed from a hipGraph.
+
+The reference's primary call is one query per request (serve_recommendations.py:206-225).  At
+Q = 1 the ~44 kernels of a request are launch-bound; libicrec's hot calls never allocate or
+synchronise, so the whole request is captured once per (token bucket, k) and replayed: the host
+does one small H2D (ids + exclusions), one graph launch and one D2H of k results.
+
+Token buckets coincide with the attention kernel's length buckets (32/64/128/256 tokens): the
+captured launch processes `bucket` rows, the real length travels in cu_seqlens on the device, so
+rows past it are computed and ignored (pooling and attention read cu_seqlens).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from .encoder import DeviceEncoder
+from .search import DeviceIndex
+
+BUCKETS = (32, 64, 128, 256)
+MAX_EXCLUDED = 1024
+
+
+class _Captured:
+    def __init__(self, enc: DeviceEncoder, index: DeviceIndex, bucket: int, k: int):
+        dev = enc.device
+        self.bucket, self.k = bucket, k
+        self.ids = torch.zeros(bucket, dtype=torch.int32, device=dev)
+        self.cu = torch.tensor([0, bucket], dtype=torch.int32, device=dev)
+        self.excl_idx = torch.zeros(MAX_EXCLUDED, dtype=torch.int32, device=dev)
+        self.excl_off = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.emb = torch.empty((1, enc.shape.hidden), dtype=torch.float32, device=dev)
+        self.out_idx = torch.empty((1, k), dtype=torch.int64, device=dev)
+        self.out_sc = torch.empty((1, k), dtype=torch.float32, device=dev)
+        # pinned staging: [ids (bucket) | cu (2) | excl_off (2) | excl_idx (MAX_EXCLUDED)]
+        self.h_in = torch.zeros(bucket + 4 + MAX_EXCLUDED, dtype=torch.int32).pin_memory()
+        self.d_in = torch.zeros_like(self.h_in, device=dev)
+        self.h_idx = torch.empty((1, k), dtype=torch.int64).pin_memory()
+        self.h_sc = torch.empty((1, k), dtype=torch.float32).pin_memory()
+
+        # the graph bakes raw pointers: it must own its scratch memory (the encoder's / index's shared
+        # workspaces are re-allocated when a later, larger un-captured call needs more room)
+        L = _native.lib()
+        self.enc_ws = torch.empty(int(L.icrec_encode_workspace_bytes(enc._h, bucket, 1)), dtype=torch.uint8, device=dev)
+        self.srch_ws = torch.empty(int(L.icrec_search_workspace_bytes(index._h, 1, k)), dtype=torch.uint8, device=dev)
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+        def body():
+            self.ids.copy_(self.d_in[:bucket])
+            self.cu.copy_(self.d_in[bucket:bucket + 2])
+            self.excl_off.copy_(self.d_in[bucket + 2:bucket + 4])
+            self.excl_idx.copy_(self.d_in[bucket + 4:])
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(L.icrec_encode(enc._h, P(self.ids), P(self.cu), 1, bucket, bucket, P(self.emb),
+                                         P(self.enc_ws), self.enc_ws.numel(), st), "icrec_encode")
+            _native.check(L.icrec_search(index._h, P(self.emb), 1, k, P(self.excl_idx), P(self.excl_off),
+                                         P(self.out_idx), P(self.out_sc), P(self.srch_ws), self.srch_ws.numel(), st),
+                          "icrec_search")
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up: function attributes, workspaces
+            body()
+            body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+
+
+class SingleRequestPath:
+    """encode + search for ONE query through a replayed hipGraph."""
+
+    def __init__(self, encoder: DeviceEncoder, index: DeviceIndex):
+        self.encoder, self.index = encoder, index
+        self._graphs: dict[tuple[int, int], _Captured] = {}
+
+    def supports(self, n_tokens: int, k: int, n_excluded: int) -> bool:
+        return 1 <= n_tokens <= BUCKETS[-1] and n_excluded <= MAX_EXCLUDED and k <= self.index.n_rows
+
+    def run(self, ids: Sequence[int], k: int, excluded_rows: Optional[Sequence[int]] = None):
+        """-> (row indices int64 [k], scores float32 [k]) on the host; -1 / 0 padded like icrec_search."""
+        n = len(ids)
+        ex = sorted(set(int(r) for r in excluded_rows)) if excluded_rows else []
+        if not self.supports(n, k, len(ex)):
+            raise ValueError("request outside the captured fast path")
+        bucket = next(b for b in BUCKETS if n <= b)
+        c = self._graphs.get((bucket, k))
+        if c is None:
+            c = self._graphs[(bucket, k)] = _Captured(self.encoder, self.index, bucket, k)
+        h = c.h_in
+        h[:n] = torch.as_tensor(ids, dtype=torch.int32)
+        h[n:bucket] = 0
+        h[bucket] = 0
+        h[bucket + 1] = n
+        h[bucket + 2] = 0
+        h[bucket + 3] = len(ex)
+        if ex:
+            h[bucket + 4:bucket + 4 + len(ex)] = torch.as_tensor(ex, dtype=torch.int32)
+        stream = torch.cuda.current_stream(self.encoder.device)
+        c.d_in.copy_(h, non_blocking=True)
+        c.graph.replay()
+        c.h_idx.copy_(c.out_idx, non_blocking=True)
+        c.h_sc.copy_(c.out_sc, non_blocking=True)
+        stream.synchronize()
+        return c.h_idx[0].numpy().copy(), c.h_sc[0].numpy().copy()

@@ -150,6 +150,11 @@ class Recommender:
         self.model = self._load_model()
         self.product_embeddings = self._load_or_build_embeddings(batch_size, use_index)
         self._index = DeviceIndex(self.product_embeddings, self.device)
+        self._fast = None
+        if os.getenv("ICREC_USE_GRAPH", "1") != "0":
+            from .fastpath import SingleRequestPath
+
+            self._fast = SingleRequestPath(self.model.encoder, self._index)
 
     # -- construction helpers (names follow the reference) ---------------------------------
     def _resolve_model_dir(self, model_dir: Path | str) -> Path | str:
@@ -250,7 +255,16 @@ class Recommender:
 
     def recommend(self, query: str, top_k: int = 10,
                   exclude_product_ids: set[str] | None = None) -> list[tuple[str, float]]:
-        """Top-k (product_id, score) by cosine similarity, best first (reference :206-225)."""
+        """Top-k (product_id, score) by cosine similarity, best first (reference :206-225).
+        One query = one hipGraph replay (fastpath.py) when ICREC_USE_GRAPH is not "0"."""
+        if self._fast is not None:
+            top_k = max(int(top_k), 1)
+            ids = self.model.tokenizer([query])[0]
+            ex = self._excluded_rows(exclude_product_ids)
+            k = min(top_k, len(self.product_ids))
+            if top_k <= _native.ICREC_MAX_K and self._fast.supports(len(ids), k, len(ex)):
+                idx, sc = self._fast.run(ids, k, ex)
+                return self._to_results(idx, sc)
         return self.recommend_batch([query], top_k, [exclude_product_ids])[0]
 
 

@@ -110,6 +110,16 @@ class DeviceIndex:
                                                  _ptr(ws), ws.numel(), _stream_ptr(self.device)), "icrec_search")
         return idx, sc
 
+    def search_into(self, q: torch.Tensor, k: int, excl_idx: Optional[torch.Tensor], excl_off: Optional[torch.Tensor],
+                    out_idx: torch.Tensor, out_score: torch.Tensor) -> None:
+        """Allocation-free form of `search` on caller-owned device buffers (hipGraph-capturable once the
+        workspace for this (Q, k) exists): q float32 [Q, dim], out_idx int64 [Q, k], out_score float32 [Q, k]."""
+        Q = int(q.shape[0])
+        ws = self._workspace(Q, k)
+        _native.check(_native.lib().icrec_search(self._h, _ptr(q), Q, k, _ptr(excl_idx), _ptr(excl_off), _ptr(out_idx),
+                                                 _ptr(out_score), _ptr(ws), ws.numel(), _stream_ptr(self.device)),
+                      "icrec_search")
+
     def search_partial(self, q, k: int, exclude: Optional[Sequence[Iterable[int]]] = None) -> torch.Tensor:
         """Shard-local sorted lists as packed keys, int64-viewed uint64 [Q,k] (see icrec_search_partial)."""
         q = self._queries(q)
