@@ -114,3 +114,32 @@ def test_bad_arguments_raise(encoder, minilm_weights):
         encoder.encode_packed(ids, cu, 300)  # longer than max_seq_length 256
     with pytest.raises(ValueError):
         encoder.encode_ids([[1, 2, 40000]])  # id outside the vocab
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+def test_wide_dynamic_range(mode):
+    """Weights 4x larger than BERT's init and LayerNorm gains of ~3: hidden activations reach tens,
+    FFN intermediates hundreds, attention is sharply peaked; tiny-magnitude weights ride along in the
+    same matrices.  The f16x3 split must stay at fp32-level agreement with the oracle."""
+    import torch
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+    from oracle import oracle
+
+    shape = syn.BertShape(vocab_size=2048, layers=2)
+    w = syn.synthetic_bert_weights(shape, seed=9, std=0.2)
+    sd = syn.blob_to_state_dict(w, shape)           # views into w
+    for name, a in sd.items():
+        if name.endswith("LayerNorm.weight"):
+            a *= 3.0
+        if name.endswith("intermediate.dense.weight"):
+            a[::7] *= 1e-4                            # rows of very small weights next to large ones
+    ids, cu = syn.synthetic_token_batch(5, seed=2, mean_len=60, std_len=40, lo=3, hi=200, vocab_size=2048)
+    want, hid = oracle.encode(w, oracle.make_cfg(vocab_size=2048, layers=2), ids, cu, return_hidden=True)
+    assert np.abs(hid).max() > 5.0                   # the stress actually stresses
+    enc = DeviceEncoder(w, shape, gemm_mode=mode)
+    got = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), int(np.diff(cu).max())).cpu().numpy()
+    err = np.abs(got - want).max()
+    print(f"[{mode}] wide-range max|emb - oracle| = {err:.3e}, max|hidden| = {np.abs(hid).max():.1f}")
+    assert err < EMB_TOL
+    enc.close()
