@@ -59,24 +59,23 @@ __device__ __forceinline__ bool excluded(const int32_t* __restrict__ ex, int lo,
 }
 
 // Merge the queue of query q into its sorted list; one wavefront, all 64 lanes call this.
+// Every element's new position is its rank in the union (keys are unique): a list entry keeps its
+// index plus the number of better candidates; candidate i gets (#better candidates) + (#better list
+// entries), the latter from a ballot over the lanes holding the list — no search, no extra LDS trips.
 __device__ __forceinline__ void merge_queue(u64* list, const u64* queue, int n, int k, int lane) {
-    u64 c = lane < n ? queue[lane] : 0ull;
-    u64 e0 = lane < k ? list[lane] : 0ull;
-    u64 e1 = lane + 64 < k ? list[lane + 64] : 0ull;
-    int rc = 0, r0 = 0, r1 = 0;
+    const u64 c = lane < n ? queue[lane] : 0ull;
+    const u64 e0 = lane < k ? list[lane] : 0ull;
+    const u64 e1 = lane + 64 < k ? list[lane + 64] : 0ull;
+    int rc = 0, r0 = 0, r1 = 0, lc = 0;
     for (int i = 0; i < n; ++i) {
-        u64 ci = queue[i];  // LDS broadcast
+        const u64 ci = queue[i];  // LDS broadcast
         rc += ci > c;
         r0 += ci > e0;
         r1 += ci > e1;
+        const int better = __popcll(__ballot(e0 > ci)) + (k > 64 ? __popcll(__ballot(e1 > ci)) : 0);
+        lc = lane == i ? better : lc;
     }
-    // number of list entries better than my candidate: binary search in the descending list
-    int lo = 0, hi = k;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (list[mid] > c) lo = mid + 1; else hi = mid;
-    }
-    const int pc = rc + lo, p0 = lane + r0, p1 = lane + 64 + r1;
+    const int pc = rc + lc, p0 = lane + r0, p1 = lane + 64 + r1;
     // all reads above are complete (their values are consumed) before any lane writes
     if (lane < n && pc < k) list[pc] = c;
     if (lane < k && p0 < k) list[p0] = e0;
@@ -150,68 +149,112 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
                     }
         }
 
-        // ---- selection: push every score that beats its query's current k-th best
-        // pend bit (j*TM+i)*16+e: score e of accumulator tile (i,j) still has to be offered
-        unsigned long long pend = 0ull;
+        // ---- selection
+        // A score is OFFERED (pushed to its query's LDS queue) when it beats the query's threshold.
+        //  * warm query (list full): threshold = current k-th best key.  Queues are merged into the
+        //    sorted lists only when one is at least half full (or at the block's last tile), so a
+        //    stale — lower — threshold only means a few extra offers, never a missed hit.
+        //  * cold query (list not full yet, threshold key 0): instead of offering all of the tile's
+        //    scores, each lane first offers only its own m largest (m = ceil(k / lanes per query) + 1,
+        //    so the lanes together offer >= k), the queues are merged at once, and a second pass
+        //    offers whatever else still beats the now-real threshold (usually nothing).
+        constexpr int LPQ = 2 * Cfg::WAVES_M;  // lanes holding scores of one query
+        const int m_local = (k + LPQ - 1) / LPQ + 1;
+        const bool last_tile = tile == t_end - 1;
+        unsigned long long offered = 0ull;
+        bool lane_cold = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            // pend bit (j*TM+i)*16+e: score e of accumulator tile (i,j) has to be offered
+            unsigned long long pend = 0ull;
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) {
-            const float thr_s = mythr[j] == ~0ull ? INFINITY : (mythr[j] ? key_score(mythr[j]) : -INFINITY);
+            for (int j = 0; j < Cfg::TN; ++j) {
+                float thr_s;
+                if (mythr[j] == ~0ull) {
+                    thr_s = INFINITY;  // padding column
+                } else if (mythr[j] == 0ull && pass == 0) {
+                    lane_cold = true;
+                    float t = INFINITY;  // t <- m-th largest distinct valid score of this lane
+                    for (int it = 0; it < m_local; ++it) {
+                        float best = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
+                        for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (acc[i][j][e] + 0.0f >= thr_s) pend |= 1ull << ((j * Cfg::TM + i) * 16 + e);
-        }
-        bool more;
-        do {
-            bool lane_pending = false;
+                            for (int e = 0; e < 16; ++e) {
+                                const bool valid = row0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane) < N;
+                                const float v = acc[i][j][e] + 0.0f;
+                                best = (valid && v < t && v > best) ? v : best;
+                            }
+                        t = best;
+                    }
+                    thr_s = t;
+                } else {
+                    thr_s = mythr[j] ? key_score(mythr[j]) : -INFINITY;
+                }
 #pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j)
+                for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) {
-                    const int sh = (j * Cfg::TM + i) * 16;
-                    unsigned m16 = (unsigned)(pend >> sh) & 0xFFFFu;
-                    while (m16) {
-                        const int e = __builtin_ctz(m16);
-                        m16 &= m16 - 1;
-                        float s = acc[i][j][0];
+                    for (int e = 0; e < 16; ++e)
+                        if (acc[i][j][e] + 0.0f >= thr_s) pend |= 1ull << ((j * Cfg::TM + i) * 16 + e);
+            }
+            pend &= ~offered;
+            offered |= pend;
+            if (pass == 0 && lane_cold) flags[2] = 1;
+            bool more, wg_cold;
+            do {
+                bool lane_pending = false;
 #pragma unroll
-                        for (int t = 1; t < 16; ++t) s = e == t ? acc[i][j][t] : s;
-                        s = s + 0.0f;  // -0 -> +0
-                        const int64_t row = row0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
-                        bool take = row < N;
-                        u64 key = 0ull;
-                        if (take) {
-                            key = make_key(s, row_base + (uint32_t)row);
-                            take = key > mythr[j];
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        const int sh = (j * Cfg::TM + i) * 16;
+                        unsigned m16 = (unsigned)(pend >> sh) & 0xFFFFu;
+                        while (m16) {
+                            const int e = __builtin_ctz(m16);
+                            m16 &= m16 - 1;
+                            float sc = acc[i][j][0];
+#pragma unroll
+                            for (int t = 1; t < 16; ++t) sc = e == t ? acc[i][j][t] : sc;
+                            sc = sc + 0.0f;  // -0 -> +0
+                            const int64_t row = row0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
+                            bool take = row < N;
+                            u64 key = 0ull;
+                            if (take) {
+                                key = make_key(sc, row_base + (uint32_t)row);
+                                take = key > mythr[j];
+                            }
+                            if (take && ex_hi[j] > ex_lo[j]) take = !excluded(excl_idx, ex_lo[j], ex_hi[j], (int)row);
+                            bool settled = true;
+                            if (take) {
+                                const int slot = atomicAdd(&cnt[myq[j]], 1);
+                                if (slot < QCAP) queue[myq[j] * QCAP + slot] = key;
+                                else { settled = false; lane_pending = true; }
+                            }
+                            if (settled) pend &= ~(1ull << (sh + e));
                         }
-                        if (take && ex_hi[j] > ex_lo[j]) take = !excluded(excl_idx, ex_lo[j], ex_hi[j], (int)row);
-                        bool settled = true;
-                        if (take) {
-                            const int slot = atomicAdd(&cnt[myq[j]], 1);
-                            if (slot < QCAP) queue[myq[j] * QCAP + slot] = key;
-                            else { settled = false; lane_pending = true; }
-                        }
-                        if (settled) pend &= ~(1ull << (sh + e));
+                    }
+                if (lane_pending) flags[round & 1] = 1;
+                __syncthreads();
+                more = flags[round & 1] != 0;
+                wg_cold = flags[2] != 0;
+                if (tid == 0) flags[(round + 1) & 1] = 0;
+                const bool force = wg_cold || last_tile;
+                // each wave merges the queues of its share of the queries
+                for (int q = wave; q < Cfg::BN; q += Cfg::THREADS / 64) {
+                    const int c = cnt[q];
+                    if (c > 0 && (force || 2 * c >= QCAP)) {
+                        merge_queue(list + (size_t)q * k, queue + q * QCAP, c < QCAP ? c : QCAP, k, lane);
+                        if (lane == 0) { thr[q] = list[(size_t)q * k + k - 1]; cnt[q] = 0; }
                     }
                 }
-            if (lane_pending) flags[round & 1] = 1;
-            __syncthreads();
-            more = flags[round & 1] != 0;
-            if (tid == 0) flags[(round + 1) & 1] = 0;
-            // each wave merges the queues of its share of the queries
-            for (int q = wave; q < Cfg::BN; q += Cfg::THREADS / 64) {
-                const int c = cnt[q];
-                if (c > 0) {
-                    merge_queue(list + (size_t)q * k, queue + q * QCAP, c < QCAP ? c : QCAP, k, lane);
-                    if (lane == 0) { thr[q] = list[(size_t)q * k + k - 1]; cnt[q] = 0; }
-                }
-            }
-            __syncthreads();
+                __syncthreads();
 #pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) mythr[j] = thr[myq[j]];
-            ++round;
-        } while (more);
+                for (int j = 0; j < Cfg::TN; ++j) mythr[j] = thr[myq[j]];
+                ++round;
+            } while (more);
+            if (!wg_cold) break;  // warm block: one pass (uniform: read between the barriers)
+        }
+        __syncthreads();
+        if (tid == 0) flags[2] = 0;
     }
 
     // sorted partial lists out
