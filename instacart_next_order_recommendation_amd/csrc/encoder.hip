@@ -353,7 +353,15 @@ __global__ __launch_bounds__(H) void pool_norm_kernel(const float* __restrict__ 
     const int s = blockIdx.x, i = threadIdx.x;
     const int t0 = cu[s], t1 = cu[s + 1];
     float acc = 0.0f;
-    for (int t = t0; t < t1; ++t) acc = acc + x[(size_t)t * H + i];
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {  // 8 independent loads in flight, summed in ascending token order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(t + u) * H + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc + v[u];
+    }
+    for (; t < t1; ++t) acc = acc + x[(size_t)t * H + i];
     float cnt = (float)(t1 - t0);
     cnt = cnt < 1e-9f ? 1e-9f : cnt;
     float val = acc / cnt;
