@@ -190,6 +190,28 @@ ICREC_API int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n
                          int32_t dim, float eps, int device, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Host tokenizer: the WordPiece stage of SentenceTransformer.encode           */
+/* (serve_recommendations.py:213,:246 -> transformers BertTokenizer ->         */
+/* tokenizers 0.22.2).  Pure host code; produces icrec_encode's packed input.  */
+/* ------------------------------------------------------------------------- */
+typedef struct icrec_tokenizer icrec_tokenizer;
+
+/* vocab_path: BERT vocab.txt (one token per line, id = line number).
+ * do_lower_case: lower-case + strip accents (all-MiniLM-L6-v2: 1).
+ * max_len: [CLS] + tokens + [SEP] is truncated to this many ids (256). */
+ICREC_API int icrec_tokenizer_create(const char* vocab_path, int do_lower_case, int max_len,
+                           icrec_tokenizer** out);
+ICREC_API int icrec_tokenizer_destroy(icrec_tokenizer* tok);
+ICREC_API int32_t icrec_tokenizer_vocab_size(const icrec_tokenizer* tok);
+
+/* Tokenise n UTF-8, NUL-terminated strings on up to n_threads host threads
+ * (<= 0: all cores).  out_cu[n+1] receives the prefix sums of the id counts and
+ * is always filled; the ids go to out_ids back to back.  Returns ICREC_ENOMEM
+ * when `cap` ids do not suffice (size the buffer from out_cu[n] and retry). */
+ICREC_API int icrec_tokenize(const icrec_tokenizer* tok, const char* const* texts, int32_t n,
+                   int32_t* out_ids, int64_t cap, int32_t* out_cu, int32_t n_threads);
+
+/* ------------------------------------------------------------------------- */
 /* Diagnostics                                                                */
 /* ------------------------------------------------------------------------- */
 ICREC_API const char* icrec_last_error(void);

@@ -24,6 +24,7 @@ EXPORTS = [
     "icrec_index_create", "icrec_index_destroy", "icrec_index_rows", "icrec_index_export",
     "icrec_search_workspace_bytes", "icrec_search", "icrec_search_partial", "icrec_merge_topk",
     "icrec_scores", "icrec_normalize_rows",
+    "icrec_tokenizer_create", "icrec_tokenizer_destroy", "icrec_tokenizer_vocab_size", "icrec_tokenize",
     "icrec_last_error", "icrec_version",
     "icrec_timing_enable", "icrec_timing_reset", "icrec_timing_query",
 ]
@@ -86,6 +87,10 @@ def lib() -> C.CDLL:
         "icrec_merge_topk": (C.c_int, [vp, i32, i32, i32, vp, vp, C.c_int, vp]),
         "icrec_scores": (C.c_int, [vp, vp, i32, vp, vp, sz, vp]),
         "icrec_normalize_rows": (C.c_int, [vp, vp, i64, i32, C.c_float, C.c_int, vp]),
+        "icrec_tokenizer_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
+        "icrec_tokenizer_destroy": (C.c_int, [vp]),
+        "icrec_tokenizer_vocab_size": (i32, [vp]),
+        "icrec_tokenize": (C.c_int, [vp, C.POINTER(C.c_char_p), i32, vp, i64, vp, i32]),
         "icrec_last_error": (C.c_char_p, []),
         "icrec_version": (C.c_char_p, []),
         "icrec_timing_enable": (C.c_int, [C.c_int]),

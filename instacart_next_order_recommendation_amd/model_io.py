@@ -33,30 +33,84 @@ class LoadedModel:
     tokenizer: "HostTokenizer"
 
 
-class HostTokenizer:
-    """BERT WordPiece tokenisation on the host ([CLS] ... [SEP], truncation to max_seq_length)."""
+class NativeTokenizer:
+    """libicrec's C++ WordPiece tokenizer (csrc/tokenizer.cpp): batched, multi-threaded, GIL-free."""
 
-    def __init__(self, model_dir: Path, max_seq_length: int):
-        from tokenizers import Tokenizer
-        from tokenizers.implementations import BertWordPieceTokenizer
+    def __init__(self, vocab_path: Path, lowercase: bool, max_seq_length: int, n_threads: int = 0):
+        import ctypes as C
+
+        from . import _native
+
+        self._C, self._native = C, _native
+        h = C.c_void_p()
+        _native.check(_native.lib().icrec_tokenizer_create(str(vocab_path).encode(), 1 if lowercase else 0,
+                                                           int(max_seq_length), C.byref(h)), "icrec_tokenizer_create")
+        self._h, self.max_seq_length, self.n_threads = h, max_seq_length, n_threads
+
+    def __call__(self, texts: Sequence[str]) -> list[list[int]]:
+        C = self._C
+        n = len(texts)
+        if n == 0:
+            return []
+        arr = (C.c_char_p * n)(*[t.replace("\x00", "").encode("utf-8", "replace") for t in texts])
+        cu = np.empty(n + 1, np.int32)
+        cap = n * self.max_seq_length
+        ids = np.empty(cap, np.int32)
+        self._native.check(self._native.lib().icrec_tokenize(self._h, arr, n, ids.ctypes.data_as(C.c_void_p), cap,
+                                                             cu.ctypes.data_as(C.c_void_p), self.n_threads),
+                           "icrec_tokenize")
+        return [ids[cu[i]:cu[i + 1]].tolist() for i in range(n)]
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self._native.lib().icrec_tokenizer_destroy(self._h)
+        except Exception:
+            pass
+
+
+class HostTokenizer:
+    """BERT WordPiece tokenisation on the host ([CLS] ... [SEP], truncation to max_seq_length).
+
+    backend "native" (default when the directory has vocab.txt): libicrec's C++ tokenizer, ~6x the
+    throughput of the Rust one on 8 cores (68k vs 11k user contexts/s) — at >50k QPS per GPU the
+    tokenizer would otherwise be the bottleneck; agrees with the Rust tokenizer on tests/test_tokenizer.py.
+    backend "tokenizers" (ICREC_TOKENIZER=tokenizers, or no vocab.txt): the Rust library the reference
+    itself ends up in."""
+
+    def __init__(self, model_dir: Path, max_seq_length: int, backend: str | None = None):
+        import os
 
         model_dir = Path(model_dir)
         tj, vt = model_dir / "tokenizer.json", model_dir / "vocab.txt"
+        backend = backend or os.getenv("ICREC_TOKENIZER") or ("native" if vt.exists() else "tokenizers")
+        lower = True
+        tc = model_dir / "tokenizer_config.json"
+        if tc.exists():
+            lower = bool(json.loads(tc.read_text()).get("do_lower_case", True))
+        self.max_seq_length = max_seq_length
+        self.backend = backend
+        if backend == "native":
+            if not vt.exists():
+                raise FileNotFoundError(f"{vt} missing: the native tokenizer needs vocab.txt")
+            self._native_tok = NativeTokenizer(vt, lower, max_seq_length)
+            return
+        if backend != "tokenizers":
+            raise ValueError(f"unknown tokenizer backend {backend!r}")
+        from tokenizers import Tokenizer
+        from tokenizers.implementations import BertWordPieceTokenizer
+
         if tj.exists():
             self._tok = Tokenizer.from_file(str(tj))
         elif vt.exists():
-            lower = True
-            tc = model_dir / "tokenizer_config.json"
-            if tc.exists():
-                lower = bool(json.loads(tc.read_text()).get("do_lower_case", True))
             self._tok = BertWordPieceTokenizer(str(vt), lowercase=lower)._tokenizer
         else:
             raise FileNotFoundError(f"{model_dir} has neither tokenizer.json nor vocab.txt")
         self._tok.no_padding()
         self._tok.enable_truncation(max_length=max_seq_length)
-        self.max_seq_length = max_seq_length
 
     def __call__(self, texts: Sequence[str]) -> list[list[int]]:
+        if self.backend == "native":
+            return self._native_tok(texts)
         return [e.ids for e in self._tok.encode_batch(list(texts))]
 
 
