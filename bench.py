@@ -233,6 +233,43 @@ def main() -> None:
         ix_tmp.close()
         catalog_tokens = int(cat_cu[-1])
 
+    # ---- the same step from TEXT in host memory (not `value`): native tokenizer on the host cores, one
+    # H2D of the packed ids, encode + search, D2H of the results — the PCIe- and tokeniser-inclusive rate
+    text_path = None
+    if rank == 0 and world == 1 and args.workload == "49k7" and not args.no_latency:
+        import tempfile
+
+        from instacart_next_order_recommendation_amd.encoder import pack_token_ids
+        from instacart_next_order_recommendation_amd.model_io import NativeTokenizer
+
+        vdir = Path(tempfile.mkdtemp(prefix="icrec_vocab_"))
+        (vdir / "vocab.txt").write_text("\n".join(syn.synthetic_vocab()) + "\n")
+        tok = NativeTokenizer(vdir / "vocab.txt", True, 256)
+        texts = syn.synthetic_user_contexts(args.batch, seed=1234)
+
+        def text_step():
+            t_a = time.perf_counter()
+            seqs = tok(texts)
+            t_b = time.perf_counter()
+            ids_t, cu_t, mx_t = pack_token_ids(seqs)
+            e = enc.encode_packed(torch.from_numpy(ids_t).to(dev), torch.from_numpy(cu_t).to(dev), mx_t)
+            i_t, s_t = search.search(e, TOP_K)
+            i_t.cpu(); s_t.cpu()
+            return t_b - t_a, int(cu_t[-1])
+
+        text_step()
+        reps, tok_s = 5, 0.0
+        t_a = time.perf_counter()
+        for _ in range(reps):
+            dt, n_tok_text = text_step()
+            tok_s += dt
+        wall = time.perf_counter() - t_a
+        text_path = {"qps": args.batch * reps / wall, "ms_per_step": wall / reps * 1e3,
+                     "tokenize_ms_per_step": tok_s / reps * 1e3, "tokens_per_step": n_tok_text,
+                     "host_threads": os.cpu_count(),
+                     "note": "synthetic user-context STRINGS -> native WordPiece on the host -> H2D -> encode -> "
+                             "search -> D2H, strictly serial (no overlap of tokenisation with GPU work)"}
+
     if rank == 0:
         q_per_step = args.batch * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -261,6 +298,7 @@ def main() -> None:
             "p50_latency_ms_single_request": p50_ms,
             "p50_latency_ms_single_request_without_hipgraph": p50_plain_ms,
             "single_request_tokens": int(cu_h[1]),
+            "from_text_in_host_memory": text_path,
             "catalog_index_build_ms": index_build_ms,
             "catalog_index_build_note": None if index_build_ms is None else
             f"encode {CATALOG_ROWS} products ({catalog_tokens} tokens, from ids in HBM) + normalise into a DeviceIndex",
