@@ -84,7 +84,9 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float) -> dic
             "peak_note": "fp32-accurate product = 3 f16 MFMAs, so the algorithm's MFMA roof is 2500/3 TFLOP/s of "
                          "algorithmic FLOPs; against the raw f16 dense peak the fraction is frac_of_f16_dense_peak",
             "frac_of_f16_dense_peak": achieved / PEAK_F16_MFMA_TFLOPS,
-            "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 1.206e9,
+            "traffic_note": "PMC per launch: 2*FETCH_SIZE 400 MB + WRITE_SIZE 806 MB (profiles/r01_pmc_hbm_bytes_f16x3.txt); "
+                            "algorithmic 1.01 GB (f16 hi/lo planes in, f16 hi/lo planes out)",
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops}
 
 
