@@ -180,6 +180,25 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same step with the product's two-stream encode (DeviceEncoder splits the batch over two HIP
+    # streams when it has the host copy of cu_seqlens, as recommend_batch does).  Reported separately: the
+    # timed region above keeps ONE icrec_encode per step so that per-kernel event times and the rocprof
+    # averages describe the same launches.
+    two_stream = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        def step2():
+            enc.encode_packed(ids_d, cu_d, max_len, out=emb, cu_host=cu_h)
+            return search.search(emb, TOP_K)
+        for _ in range(3):
+            step2()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(10):
+            step2()
+        torch.cuda.synchronize(dev)
+        dt2 = (time.perf_counter() - t2) / 10
+        two_stream = {"qps": args.batch / dt2, "ms_per_step": dt2 * 1e3}
+
     # ---- single-request latency (Q = 1): what Recommender.recommend() does per request, host-timed
     # from token ids in host memory to k results in host memory.  (a) hipGraph replay (fastpath.py,
     # the product path), (b) the same two library calls launched kernel by kernel.
@@ -300,6 +319,7 @@ def main() -> None:
             "p50_latency_ms_single_request": p50_ms,
             "p50_latency_ms_single_request_without_hipgraph": p50_plain_ms,
             "single_request_tokens": int(cu_h[1]),
+            "with_two_stream_encode": two_stream,
             "from_text_in_host_memory": text_path,
             "catalog_index_build_ms": index_build_ms,
             "catalog_index_build_note": None if index_build_ms is None else

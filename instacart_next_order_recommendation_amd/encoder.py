@@ -38,6 +38,9 @@ def pack_token_ids(seqs: Sequence[Sequence[int]]):
 class DeviceEncoder:
     """all-MiniLM-L6-v2-shaped BERT encoder resident on one GPU."""
 
+    SPLIT_MIN_SEQS = 128       # two-stream split only when each half has at least this many sequences ...
+    SPLIT_MIN_TOKENS = 16384   # ... and this many tokens (enough blocks to fill the chip on its own)
+
     def __init__(self, weights: np.ndarray, shape: BertShape = BertShape(), device: str | torch.device = "cuda:0",
                  gemm_mode: Optional[str] = None):
         """gemm_mode: "f32" (exact f32 MFMA, bit-identical GEMMs) or "f16x3" (3-term split on the f16
@@ -65,7 +68,9 @@ class DeviceEncoder:
         _native.check(L.icrec_encoder_create(w.ctypes.data_as(C.c_void_p), w.size, C.byref(self._cfg),
                                              self.device.index, C.byref(h)), "icrec_encoder_create")
         self._h = h
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_slots: dict[int, Optional[torch.Tensor]] = {}
+        self._side: Optional[torch.cuda.Stream] = None
+        self._split_cu = None
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -78,16 +83,30 @@ class DeviceEncoder:
         except Exception:
             pass
 
-    def _workspace(self, total_tokens: int, n_seqs: int) -> torch.Tensor:
+    def _workspace(self, total_tokens: int, n_seqs: int, slot: int = 0) -> torch.Tensor:
         need = int(_native.lib().icrec_encode_workspace_bytes(self._h, total_tokens, n_seqs))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._ws_slots.get(slot)
+        if ws is None or ws.numel() < need:
+            self._ws_slots[slot] = None
+            ws = self._ws_slots[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def _encode_call(self, ids: torch.Tensor, cu: torch.Tensor, n: int, T: int, max_seqlen: int, out: torch.Tensor,
+                     slot: int) -> None:
+        ws = self._workspace(T, n, slot)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _native.check(_native.lib().icrec_encode(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(cu.data_ptr()), n, T,
+                                                 int(max_seqlen), C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(ws.data_ptr()), ws.numel(), st), "icrec_encode")
 
     def encode_packed(self, ids: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen: int,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Device tensors in (int32 ids[T], int32 cu_seqlens[n+1]) -> float32 [n, hidden] on the device."""
+                      out: Optional[torch.Tensor] = None, cu_host: Optional[np.ndarray] = None) -> torch.Tensor:
+        """Device tensors in (int32 ids[T], int32 cu_seqlens[n+1]) -> float32 [n, hidden] on the device.
+
+        With `cu_host` (the host copy of cu_seqlens) and a large batch, the two halves of the batch run
+        concurrently on two HIP streams (own workspaces, fork/join by events): one half's bandwidth-bound
+        kernels overlap the other half's MFMA-bound GEMMs (-6 % per batch of 1,024 contexts).  Results are
+        identical: every kernel is per-sequence / per-token."""
         if ids.dtype != torch.int32 or cu_seqlens.dtype != torch.int32:
             raise TypeError("ids and cu_seqlens must be int32")
         ids = ids.to(self.device).contiguous()
@@ -95,11 +114,23 @@ class DeviceEncoder:
         n, T = int(cu.numel()) - 1, int(ids.numel())
         if out is None:
             out = torch.empty((n, self.shape.hidden), dtype=torch.float32, device=self.device)
-        ws = self._workspace(T, n)
-        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _native.check(_native.lib().icrec_encode(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(cu.data_ptr()), n, T,
-                                                 int(max_seqlen), C.c_void_p(out.data_ptr()),
-                                                 C.c_void_p(ws.data_ptr()), ws.numel(), st), "icrec_encode")
+        if cu_host is None or n < 2 * self.SPLIT_MIN_SEQS or T < 2 * self.SPLIT_MIN_TOKENS:
+            self._encode_call(ids, cu, n, T, max_seqlen, out, 0)
+            return out
+        half = n // 2
+        t_half = int(cu_host[half])
+        key = (cu.data_ptr(), half, t_half)
+        if self._split_cu is None or self._split_cu[0] != key:   # second half's rebased cu_seqlens (cached)
+            self._split_cu = (key, (cu[half:] - t_half).contiguous())
+        cu_b = self._split_cu[1]
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._encode_call(ids[t_half:], cu_b, n - half, T - t_half, max_seqlen, out[half:], 1)
+        self._encode_call(ids[:t_half], cu[: half + 1], half, t_half, max_seqlen, out[:half], 0)
+        main.wait_stream(self._side)
         return out
 
     def encode_ids(self, seqs: Sequence[Sequence[int]], max_tokens_per_call: int = 1 << 18) -> torch.Tensor:
@@ -118,6 +149,7 @@ class DeviceEncoder:
             if ids.min() < 0 or vmax >= self.shape.vocab_size:
                 raise ValueError(f"token id out of range [0, {self.shape.vocab_size})")
             self.encode_packed(torch.from_numpy(ids).to(self.device, non_blocking=True),
-                               torch.from_numpy(cu).to(self.device, non_blocking=True), mx, out=out[start:end])
+                               torch.from_numpy(cu).to(self.device, non_blocking=True), mx, out=out[start:end],
+                               cu_host=cu)
             start = end
         return out

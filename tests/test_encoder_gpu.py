@@ -143,3 +143,17 @@ def test_wide_dynamic_range(mode):
     print(f"[{mode}] wide-range max|emb - oracle| = {err:.3e}, max|hidden| = {np.abs(hid).max():.1f}")
     assert err < EMB_TOL
     enc.close()
+
+
+def test_two_stream_split_is_bitwise_identical(encoder):
+    """encode_packed with cu_host splits a large batch over two HIP streams: same bits as one call."""
+    import torch
+    from instacart_next_order_recommendation_amd import synthetic as syn
+
+    ids, cu = syn.synthetic_token_batch(300, seed=4, mean_len=120, std_len=50, lo=4, hi=256)
+    i_d, c_d = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
+    mx = int(np.diff(cu).max())
+    one = encoder.encode_packed(i_d, c_d, mx).cpu().numpy()
+    for _ in range(2):
+        two = encoder.encode_packed(i_d, c_d, mx, cu_host=cu).cpu().numpy()
+        np.testing.assert_array_equal(one, two)
