@@ -341,6 +341,188 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------- attention, f16x3 arithmetic
+// Same structure as attention_kernel (one block per (sequence, head), S^T on the accumulator rows, P fed
+// back from the accumulators), with both products on the f16 MFMA by the 3-term split of gemm_x3.h:
+//   S^T = K_hi.Q_hi + 2^-11 (K_hi.Q_lo + K_lo.Q_hi)        O = P_hi.V_hi + 2^-11 (P_hi.V_lo + P_lo.V_hi)
+// K is staged as hi/lo f16 planes [key][32] (64-B rows, 16-B chunks XOR-swizzled by (key>>2)&3), V as
+// TRANSPOSED hi/lo planes [dim][key] so that a lane's eight k-slots (keys) of one head dim are two 8-B
+// reads; Q (per wave) and P (per tile, straight from the accumulators) are split in registers.
+// For a 32-key tile and k-step s, slot j of lane-half h is key 4h + (j&3) + 8(2s + (j>>2)) — the keys
+// accumulator register e = 8s + j holds — on both operands.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 a = (_Float16)x[j];
+        hi[j] = a;
+        lo[j] = (_Float16)((x[j] - (float)a) * LO_SCALE);
+    }
+}
+
+template <int NKT, int WAVES, bool SPLIT>
+__global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* __restrict__ qkv,
+                                                                  const int32_t* __restrict__ cu, int heads, int H,
+                                                                  float scale_log2e, float* __restrict__ ctx,
+                                                                  _Float16* __restrict__ ch, _Float16* __restrict__ cl) {
+    constexpr int VT = NKT * 32 + 4;  // V^T row stride in halfs (+8 B: the 32 dims land on distinct banks)
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[NKT * 32 * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[NKT * 32 * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VT];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[32 * VT];
+    __shared__ float Ls[WAVES * 32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int t0 = cu[s], L = cu[s + 1] - t0;
+    const int nkt = (L + 31) >> 5;
+    if (nkt > NKT || (NKT > 1 && nkt <= NKT / 2)) return;  // another bucket's sequence
+    const int qb0 = blockIdx.y * WAVES;
+    if (qb0 >= nkt) return;
+    const int ld = 3 * H;
+
+    for (int id = tid; id < nkt * 32 * 8; id += WAVES * 64) {
+        const int key = id >> 3, c = id & 7;  // c: 4-dim group
+        const int rr = key < L ? key : L - 1;
+        const float* src = qkv + (size_t)(t0 + rr) * ld + hd * DH + c * 4;
+        const float4 kv = *reinterpret_cast<const float4*>(src + H);
+        const float4 vv = *reinterpret_cast<const float4*>(src + 2 * H);
+        half4 khi, klo;
+        const float kx[4] = {kv.x, kv.y, kv.z, kv.w}, vx[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            _Float16 a, b;
+            split_f16(kx[i], a, b);
+            khi[i] = a; klo[i] = b;
+            split_f16(vx[i], a, b);
+            Vh[(c * 4 + i) * VT + key] = a;
+            Vl[(c * 4 + i) * VT + key] = b;
+        }
+        const int off = key * 32 + ((((c >> 1) ^ ((key >> 2) & 3)) << 3) | ((c & 1) << 2));
+        *reinterpret_cast<half4*>(Kh + off) = khi;
+        *reinterpret_cast<half4*>(Kl + off) = klo;
+    }
+    const int r = lane & 31, h = lane >> 5;
+    const int qb = qb0 + wave;
+    half8 qh[2], ql[2];  // B operand of S^T: this lane's query row, dims 16s + 8h .. +7
+    {
+        int qr = qb * 32 + r;
+        qr = qr < L ? qr : L - 1;
+        const float* qp = qkv + (size_t)(t0 + qr) * ld + hd * DH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * h);
+            const float4 b = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * h + 4);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            split8(x, qh[ks], ql[ks]);
+        }
+    }
+    __syncthreads();
+    if (qb >= nkt) return;  // idle wave (no barrier below)
+
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
+        if (kt < nkt) {
+            f32x16 a1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a1[e] = 0.0f;
+            const int key = kt * 32 + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = key * 32 + (((2 * ks + h) ^ ((key >> 2) & 3)) << 3);
+                const half8 kh = *reinterpret_cast<const half8*>(Kh + off);
+                const half8 kl = *reinterpret_cast<const half8*>(Kl + off);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sc[kt], 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[kt][e] = fmaf(a1[e], LO_UNSCALE, sc[kt][e]);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+            const bool last = kt == nkt - 1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = sc[kt][e] * scale_log2e;
+                if (last && kt * 32 + acc_row(e, lane) >= L) v = -INFINITY;
+                sc[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float lsum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
+                sc[kt][e] = p;
+                lsum = lsum + p;
+            }
+        }
+    }
+    {
+        const float other = __shfl_xor(lsum, 32, 64);
+        lsum = h == 0 ? lsum + other : other + lsum;
+    }
+    if (h == 0) Ls[wave * 32 + r] = lsum;
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.0f; o1[e] = 0.0f; }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float px[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[j] = sc[kt][8 * ks + j];
+                half8 ph, pl;
+                split8(px, ph, pl);
+                // this lane's head dim r, keys base .. base+3 and base+8 .. base+11
+                const int base = kt * 32 + 4 * h + 16 * ks;
+                const half4 v0h = *reinterpret_cast<const half4*>(Vh + r * VT + base);
+                const half4 v1h = *reinterpret_cast<const half4*>(Vh + r * VT + base + 8);
+                const half4 v0l = *reinterpret_cast<const half4*>(Vl + r * VT + base);
+                const half4 v1l = *reinterpret_cast<const half4*>(Vl + r * VT + base + 8);
+                const half8 vh = {v0h[0], v0h[1], v0h[2], v0h[3], v1h[0], v1h[1], v1h[2], v1h[3]};
+                const half8 vl = {v0l[0], v0l[1], v0l[2], v0l[3], v1l[0], v1l[1], v1l[2], v1l[3]};
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int qrow = acc_row(e, lane);
+        const int tq = qb * 32 + qrow;
+        if (tq < L) {
+            const float v = fmaf(o1[e], LO_UNSCALE, o0[e]) / Ls[wave * 32 + qrow];
+            const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
+            if (SPLIT) {
+                _Float16 hi, lo;
+                split_f16(v, hi, lo);
+                ch[at] = hi;
+                cl[at] = lo;
+            } else {
+                ctx[at] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- mean pooling + L2 normalise
 // sentence_transformers Pooling(mean): sum_t h_t / clamp(count, 1e-9); then n_norm times
 // x / max(|x|_2, 1e-12) (Normalize module, normalize_embeddings=True).  One workgroup of
@@ -454,21 +636,23 @@ static int launch_linear_x3(const _Float16* Ah, const _Float16* Al, int M, int K
 
 // Launch every length bucket that can occur for max_seqlen (a bucket whose workgroups all exit
 // costs a few microseconds; single-sequence calls launch exactly one bucket).
-template <bool SPLIT>
+template <bool SPLIT, bool X3>
 static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
                              float* ctx, _Float16* ch, _Float16* cl, hipStream_t st) {
     const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
     const int nkt_max = (max_seqlen + 31) / 32;
     const bool single = n_seqs == 1;
     const dim3 grid1(n_seqs * heads, 1);
-    if (single ? nkt_max == 1 : true)
-        hipLaunchKernelGGL((attention_kernel<1, 1, SPLIT>), grid1, dim3(64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
-    if (single ? nkt_max == 2 : nkt_max >= 2)
-        hipLaunchKernelGGL((attention_kernel<2, 2, SPLIT>), grid1, dim3(128), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
-    if (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)
-        hipLaunchKernelGGL((attention_kernel<4, 4, SPLIT>), grid1, dim3(256), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
-    if (nkt_max >= 5)
-        hipLaunchKernelGGL((attention_kernel<8, 8, SPLIT>), grid1, dim3(512), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);
+#define ICREC_ATT(NKT, W)                                                                                        \
+    do {                                                                                                         \
+        if (X3) hipLaunchKernelGGL((attention_x3_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl); \
+        else hipLaunchKernelGGL((attention_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);      \
+    } while (0)
+    if (single ? nkt_max == 1 : true) ICREC_ATT(1, 1);
+    if (single ? nkt_max == 2 : nkt_max >= 2) ICREC_ATT(2, 2);
+    if (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3) ICREC_ATT(4, 4);
+    if (nkt_max >= 5) ICREC_ATT(8, 8);
+#undef ICREC_ATT
 }
 
 }  // namespace icrec
@@ -613,7 +797,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
         if (x3) {
             int rc = launch_linear_x3<0>(xh, xl, T, H, L.Wqkv_h, L.Wqkv_l, 3 * H, L.bqkv, qkv, nullptr, nullptr, st);
             if (rc != ICREC_OK) return rc;
-            launch_attention<true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
             launch_linear_x3<0>(ch, cl, T, H, L.Wo_h, L.Wo_l, H, L.bo, t1, nullptr, nullptr, st);
             hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
                                c.ln_eps, xh, xl);
@@ -627,7 +811,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                                c.ln_eps, xh, xl);
         } else {
             launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
-            launch_attention<false>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            launch_attention<false, false>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
             launch_linear<false>(ctx, T, H, L.Wo, H, L.bo, t1, st);
             hipLaunchKernelGGL((add_ln_kernel<HID, false>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
                                c.ln_eps, xh, xl);
