@@ -382,6 +382,21 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
     if (qb0 >= nkt) return;
     const int ld = 3 * H;
 
+    const int r = lane & 31, h = lane >> 5;
+    const int qb = qb0 + wave;
+    half8 qh[2], ql[2];  // B operand of S^T: this lane's query row, dims 16s + 8h .. +7
+    {
+        int qr = qb * 32 + r;
+        qr = qr < L ? qr : L - 1;
+        const float* qp = qkv + (size_t)(t0 + qr) * ld + hd * DH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * h);
+            const float4 b = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * h + 4);
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            split8(x, qh[ks], ql[ks]);
+        }
+    }
     for (int id = tid; id < nkt * 32 * 8; id += WAVES * 64) {
         const int key = id >> 3, c = id & 7;  // c: 4-dim group
         const int rr = key < L ? key : L - 1;
@@ -402,21 +417,6 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
         const int off = key * 32 + ((((c >> 1) ^ ((key >> 2) & 3)) << 3) | ((c & 1) << 2));
         *reinterpret_cast<half4*>(Kh + off) = khi;
         *reinterpret_cast<half4*>(Kl + off) = klo;
-    }
-    const int r = lane & 31, h = lane >> 5;
-    const int qb = qb0 + wave;
-    half8 qh[2], ql[2];  // B operand of S^T: this lane's query row, dims 16s + 8h .. +7
-    {
-        int qr = qb * 32 + r;
-        qr = qr < L ? qr : L - 1;
-        const float* qp = qkv + (size_t)(t0 + qr) * ld + hd * DH;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const float4 a = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * h);
-            const float4 b = *reinterpret_cast<const float4*>(qp + 16 * ks + 8 * h + 4);
-            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            split8(x, qh[ks], ql[ks]);
-        }
     }
     __syncthreads();
     if (qb >= nkt) return;  // idle wave (no barrier below)
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
         const int qrow = acc_row(e, lane);
         const int tq = qb * 32 + qrow;
         if (tq < L) {
-            const float v = fmaf(o1[e], LO_UNSCALE, o0[e]) / Ls[wave * 32 + qrow];
+            const float v = fmaf(o1[e], LO_UNSCALE, o0[e]) * __builtin_amdgcn_rcpf(Ls[wave * 32 + qrow]);
             const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
             if (SPLIT) {
                 _Float16 hi, lo;
