@@ -372,6 +372,7 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
     __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VT];
     __shared__ __attribute__((aligned(16))) _Float16 Vl[32 * VT];
     __shared__ float Ls[WAVES * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Ob[(SPLIT && NKT >= 8) ? WAVES * 2 * 32 * 32 : 8];  // per-wave output tile (hi | lo), long bucket only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
@@ -504,20 +505,45 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
             }
         }
     }
+    if (SPLIT && NKT >= 8) {
+        // park the wave's 32 x 32 output tile (hi and lo planes) in LDS row-major, then write it out 16 B
+        // per lane: 4 store instructions instead of 32 two-byte ones
+        _Float16* ob = Ob + wave * (2 * 32 * 32);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int qrow = acc_row(e, lane);
-        const int tq = qb * 32 + qrow;
-        if (tq < L) {
+        for (int e = 0; e < 16; ++e) {
+            const int qrow = acc_row(e, lane);
             const float v = fmaf(o1[e], LO_UNSCALE, o0[e]) * __builtin_amdgcn_rcpf(Ls[wave * 32 + qrow]);
-            const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
-            if (SPLIT) {
-                _Float16 hi, lo;
-                split_f16(v, hi, lo);
-                ch[at] = hi;
-                cl[at] = lo;
-            } else {
-                ctx[at] = v;
+            _Float16 hi, lo;
+            split_f16(v, hi, lo);
+            ob[qrow * 32 + r] = hi;
+            ob[32 * 32 + qrow * 32 + r] = lo;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int id = lane + 64 * t, qrow = id >> 2, c8 = (id & 3) * 8;
+            const int tq = qb * 32 + qrow;
+            if (tq < L) {
+                const size_t at = (size_t)(t0 + tq) * H + hd * DH + c8;
+                *reinterpret_cast<u32x4*>(ch + at) = *reinterpret_cast<const u32x4*>(ob + qrow * 32 + c8);
+                *reinterpret_cast<u32x4*>(cl + at) = *reinterpret_cast<const u32x4*>(ob + 32 * 32 + qrow * 32 + c8);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qrow = acc_row(e, lane);
+            const int tq = qb * 32 + qrow;
+            if (tq < L) {
+                const float v = fmaf(o1[e], LO_UNSCALE, o0[e]) * __builtin_amdgcn_rcpf(Ls[wave * 32 + qrow]);
+                const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
+                if (SPLIT) {
+                    _Float16 hi, lo;
+                    split_f16(v, hi, lo);
+                    ch[at] = hi;
+                    cl[at] = lo;
+                } else {
+                    ctx[at] = v;
+                }
             }
         }
     }
