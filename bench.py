@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="user contexts per GPU per step")
     ap.add_argument("--workload", default="49k7", choices=["49k7", "10m"])
+    ap.add_argument("--catalog-rows", default=None, choices=["f32", "bf16"],
+                    help="how the index keeps its rows in HBM (default: f32 for 49k7, bf16 for 10m as BASELINE configs[4] says)")
     ap.add_argument("--gemm-mode", default=None, choices=["f32", "f16x3"],
                     help="encoder GEMM arithmetic (default: the package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,7 +141,8 @@ def main() -> None:
             m = min(1 << 18, hi - lo - s)
             cid = torch.randint(0, 200, (m,), device=dev, generator=g)
             shard[s:s + m] = centres[cid] + 0.35 * torch.randn(m, shape.hidden, device=dev, generator=g)
-    backend = HipShardBackend(shard, lo, dev)
+    row_storage = args.catalog_rows or ("f32" if args.workload == "49k7" else "bf16")
+    backend = HipShardBackend(shard, lo, dev, storage=row_storage)
     del shard
     search = ShardedSearch(backend, lo, hi)
 
@@ -308,7 +311,8 @@ def main() -> None:
             "config": {
                 "workload": ("BASELINE configs[1]/[2]: encode + cos_sim + top-20 over the 49,688-row catalog, "
                              f"{args.batch} user contexts per GPU per step") if args.workload == "49k7" else
-                            "BASELINE configs[4]: 10M x 384 fp32 synthetic catalog, row-sharded",
+                            f"BASELINE configs[4]: 10M x 384 synthetic catalog kept as {row_storage} rows, row-sharded",
+                "catalog_row_storage": row_storage,
                 "catalog_rows": n_rows, "dim": shape.hidden, "top_k": TOP_K,
                 "contexts_per_gpu_per_step": args.batch, "tokens_per_gpu_per_step": total_tokens,
                 "mean_tokens_per_context": total_tokens / args.batch, "max_tokens": max_len,

@@ -129,11 +129,24 @@ ICREC_API int icrec_encode(icrec_encoder* enc,
  * `row_offset` is added to every returned row index (catalog shards).        */
 ICREC_API int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim,
                        int64_t row_offset, int device, icrec_index** out);
+
+/* Same, choosing how the normalised rows are kept in HBM (BASELINE config 5: a 10M x 384
+ * bf16 catalog, 7.68 GB instead of 15.4 GB):
+ *   ICREC_ROWS_F32   the fp32 quotient itself (what icrec_index_create does);
+ *   ICREC_ROWS_BF16  the fp32 quotient rounded to bfloat16, round-to-nearest-even.
+ * Only the storage changes: scores are still the fp32 fmaf chain over k of
+ * q_hat[k] * float(row[k]) on the exact-f32 MFMA, so results are bit-identical to
+ * oracle/icrec_oracle.c:icrec_oracle_search_bf16 (same rounded rows, same chain).       */
+#define ICREC_ROWS_F32 0
+#define ICREC_ROWS_BF16 1
+ICREC_API int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim,
+                          int64_t row_offset, int device, int32_t storage, icrec_index** out);
 ICREC_API int icrec_index_destroy(icrec_index* idx);
 ICREC_API int64_t icrec_index_rows(const icrec_index* idx);
+ICREC_API int32_t icrec_index_storage(const icrec_index* idx); /* ICREC_ROWS_* (-1: NULL handle) */
 
-/* Copy the normalised rows back out (row-major fp32 [n_rows, dim]); used by the
- * parity tests and by EmbeddingIndex.save.                                   */
+/* Copy the normalised rows back out (row-major fp32 [n_rows, dim]; bf16 storage is
+ * widened exactly); used by the parity tests and by EmbeddingIndex.save.     */
 ICREC_API int icrec_index_export(const icrec_index* idx, float* rows_dev, void* stream);
 
 ICREC_API size_t icrec_search_workspace_bytes(const icrec_index* idx, int32_t n_queries,

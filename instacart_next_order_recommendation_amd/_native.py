@@ -21,7 +21,8 @@ GEMM_MODES = {"f32": GEMM_F32, "f16x3": GEMM_F16X3}
 EXPORTS = [
     "icrec_encoder_weight_count", "icrec_encoder_create", "icrec_encoder_destroy",
     "icrec_encode_workspace_bytes", "icrec_encode",
-    "icrec_index_create", "icrec_index_destroy", "icrec_index_rows", "icrec_index_export",
+    "icrec_index_create", "icrec_index_create_ex", "icrec_index_destroy", "icrec_index_rows", "icrec_index_storage",
+    "icrec_index_export",
     "icrec_search_workspace_bytes", "icrec_search", "icrec_search_partial", "icrec_merge_topk",
     "icrec_scores", "icrec_normalize_rows",
     "icrec_tokenizer_create", "icrec_tokenizer_destroy", "icrec_tokenizer_vocab_size", "icrec_tokenize",
@@ -78,6 +79,8 @@ def lib() -> C.CDLL:
         "icrec_encode_workspace_bytes": (sz, [vp, i64, i32]),
         "icrec_encode": (C.c_int, [vp, vp, vp, i32, i64, i32, vp, vp, sz, vp]),
         "icrec_index_create": (C.c_int, [vp, i64, i32, i64, C.c_int, C.POINTER(vp)]),
+        "icrec_index_create_ex": (C.c_int, [vp, i64, i32, i64, C.c_int, i32, C.POINTER(vp)]),
+        "icrec_index_storage": (i32, [vp]),
         "icrec_index_destroy": (C.c_int, [vp]),
         "icrec_index_rows": (i64, [vp]),
         "icrec_index_export": (C.c_int, [vp, vp, vp]),

@@ -113,24 +113,40 @@ struct TileCfg {
     static_assert(BM * 8 % THREADS == 0 && BN * 8 % THREADS == 0, "tile/threads mismatch");
 };
 
-template <class Cfg>
+// A16: operand A (the catalog rows in the search kernel) is stored as bfloat16; a thread's chunk is
+// then 16 B = 8 consecutive k (half as many chunks), widened to fp32 when it is written to LDS.
+template <class Cfg, bool A16 = false>
 struct TileRegs {
-    float4 a[Cfg::A_CHUNKS];
+    static constexpr int A_N = A16 ? (Cfg::A_CHUNKS + 1) / 2 : Cfg::A_CHUNKS;
+    float4 a[A_N];
     float4 b[Cfg::B_CHUNKS];
 };
 
 // Issue the global loads of slab `slab` (rows clamped to the last valid row).
-template <class Cfg>
-__device__ __forceinline__ void tile_load(TileRegs<Cfg>& r, const float* __restrict__ A, int64_t a_row0,
+template <class Cfg, bool A16 = false>
+__device__ __forceinline__ void tile_load(TileRegs<Cfg, A16>& r, const void* __restrict__ Av, int64_t a_row0,
                                           int64_t a_rows, const float* __restrict__ B, int64_t b_row0,
                                           int64_t b_rows, int K, int slab) {
     const int t = threadIdx.x;
+    if (A16) {
+        static_assert(!A16 || Cfg::BM * 4 % Cfg::THREADS == 0, "tile/threads mismatch (bf16 rows)");
+        const uint16_t* A = static_cast<const uint16_t*>(Av);
 #pragma unroll
-    for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
-        int id = t + Cfg::THREADS * i;
-        int64_t row = a_row0 + (id >> 3);
-        row = row < a_rows ? row : a_rows - 1;
-        r.a[i] = *reinterpret_cast<const float4*>(A + row * K + slab * BK + (id & 7) * 4);
+        for (int i = 0; i < TileRegs<Cfg, A16>::A_N; ++i) {
+            int id = t + Cfg::THREADS * i;
+            int64_t row = a_row0 + (id >> 2);
+            row = row < a_rows ? row : a_rows - 1;
+            r.a[i] = *reinterpret_cast<const float4*>(A + row * K + slab * BK + (id & 3) * 8);  // raw bits
+        }
+    } else {
+        const float* A = static_cast<const float*>(Av);
+#pragma unroll
+        for (int i = 0; i < TileRegs<Cfg, A16>::A_N; ++i) {
+            int id = t + Cfg::THREADS * i;
+            int64_t row = a_row0 + (id >> 3);
+            row = row < a_rows ? row : a_rows - 1;
+            r.a[i] = *reinterpret_cast<const float4*>(A + row * K + slab * BK + (id & 7) * 4);
+        }
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
@@ -142,16 +158,33 @@ __device__ __forceinline__ void tile_load(TileRegs<Cfg>& r, const float* __restr
 }
 
 // Write the staged slab into LDS in the even/odd-split order.
-template <class Cfg>
-__device__ __forceinline__ void tile_store_lds(const TileRegs<Cfg>& r, float* As, float* Bs) {
+template <class Cfg, bool A16 = false>
+__device__ __forceinline__ void tile_store_lds(const TileRegs<Cfg, A16>& r, float* As, float* Bs) {
     const int t = threadIdx.x;
+    if (A16) {
 #pragma unroll
-    for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
-        int id = t + Cfg::THREADS * i;
-        int row = id >> 3, c = id & 7;
-        float* p = As + row * LDK + (c >> 1) * 8 + (c & 1) * 2;
-        *reinterpret_cast<float2*>(p) = make_float2(r.a[i].x, r.a[i].z);      // even k
-        *reinterpret_cast<float2*>(p + 4) = make_float2(r.a[i].y, r.a[i].w);  // odd k
+        for (int i = 0; i < TileRegs<Cfg, A16>::A_N; ++i) {
+            int id = t + Cfg::THREADS * i;
+            int row = id >> 2, c = id & 3;
+            // word w holds k = 2w (low half) and k = 2w+1 (high half); bf16 -> fp32 is a 16-bit shift
+            const unsigned w0 = __float_as_uint(r.a[i].x), w1 = __float_as_uint(r.a[i].y),
+                           w2 = __float_as_uint(r.a[i].z), w3 = __float_as_uint(r.a[i].w);
+            float* p = As + row * LDK + c * 8;
+            *reinterpret_cast<float4*>(p) = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w1 << 16),
+                                                        __uint_as_float(w2 << 16), __uint_as_float(w3 << 16));
+            *reinterpret_cast<float4*>(p + 4) =
+                make_float4(__uint_as_float(w0 & 0xFFFF0000u), __uint_as_float(w1 & 0xFFFF0000u),
+                            __uint_as_float(w2 & 0xFFFF0000u), __uint_as_float(w3 & 0xFFFF0000u));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TileRegs<Cfg, A16>::A_N; ++i) {
+            int id = t + Cfg::THREADS * i;
+            int row = id >> 3, c = id & 7;
+            float* p = As + row * LDK + (c >> 1) * 8 + (c & 1) * 2;
+            *reinterpret_cast<float2*>(p) = make_float2(r.a[i].x, r.a[i].z);      // even k
+            *reinterpret_cast<float2*>(p + 4) = make_float2(r.a[i].y, r.a[i].w);  // odd k
+        }
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
@@ -192,11 +225,11 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[Cfg::TM][Cfg::TN], const 
 // Full K loop for one output tile: single LDS buffer, register prefetch of the next slab
 // under the current slab's MFMAs.  `pre` must already hold slab 0 on entry when
 // `preloaded` is true (lets a caller overlap the first loads with its own epilogue).
-template <class Cfg>
-__device__ __forceinline__ void tile_gemm(f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* __restrict__ A,
+template <class Cfg, bool A16 = false>
+__device__ __forceinline__ void tile_gemm(f32x16 (&acc)[Cfg::TM][Cfg::TN], const void* __restrict__ A,
                                           int64_t a_row0, int64_t a_rows, const float* __restrict__ B,
                                           int64_t b_row0, int64_t b_rows, int K, float* As, float* Bs,
-                                          TileRegs<Cfg>& pre, bool preloaded) {
+                                          TileRegs<Cfg, A16>& pre, bool preloaded) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
 #pragma unroll
@@ -206,12 +239,12 @@ __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[Cfg::TM][Cfg::TN], const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     const int nslab = K / BK;
-    if (!preloaded) tile_load<Cfg>(pre, A, a_row0, a_rows, B, b_row0, b_rows, K, 0);
+    if (!preloaded) tile_load<Cfg, A16>(pre, A, a_row0, a_rows, B, b_row0, b_rows, K, 0);
     for (int s = 0; s < nslab; ++s) {
         __syncthreads();  // previous slab's LDS reads are done
-        tile_store_lds<Cfg>(pre, As, Bs);
+        tile_store_lds<Cfg, A16>(pre, As, Bs);
         __syncthreads();
-        if (s + 1 < nslab) tile_load<Cfg>(pre, A, a_row0, a_rows, B, b_row0, b_rows, K, s + 1);
+        if (s + 1 < nslab) tile_load<Cfg, A16>(pre, A, a_row0, a_rows, B, b_row0, b_rows, K, s + 1);
         tile_mma<Cfg>(acc, As, Bs, wm, wn, lane);
     }
 }

@@ -14,13 +14,29 @@ namespace icrec {
 // out = x / max(|x|_2, eps) — torch.nn.functional.normalize(p=2, dim=1) as cos_sim applies it.
 // One wavefront per row; reduction order = 64 strided fmaf partials + xor butterfly, identical
 // to oracle/icrec_oracle.c:wave_sum(mode 2).
-__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                             int64_t n_rows, int64_t n_out_rows, int dim, float eps) {
+// float -> bfloat16 bits, round to nearest even (inputs are finite: normalised rows)
+__device__ __forceinline__ uint16_t bf16_rne(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// tr_cols > 0 (fp32 only): write the result transposed, out[i * tr_cols + row] (n_out_rows == tr_cols) — the
+// k-major query layout of stream_search_kernel.
+template <bool OUT16>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, void* __restrict__ outv,
+                                                             int64_t n_rows, int64_t n_out_rows, int dim, float eps,
+                                                             int tr_cols = 0) {
+    float* out = static_cast<float*>(outv);
+    uint16_t* out16 = static_cast<uint16_t*>(outv);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_out_rows) return;
     if (row >= n_rows) {  // zero padding rows (query tiles are padded to the tile width)
-        for (int i = lane; i < dim; i += 64) out[row * dim + i] = 0.0f;
+        for (int i = lane; i < dim; i += 64) {
+            if (OUT16) out16[row * dim + i] = 0;
+            else if (tr_cols > 0) out[(int64_t)i * tr_cols + row] = 0.0f;
+            else out[row * dim + i] = 0.0f;
+        }
         return;
     }
     const float* xr = x + row * dim;
@@ -31,7 +47,18 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     }
     float nrm = sqrtf(wave_sum_f32(acc));
     float den = nrm > eps ? nrm : eps;
-    for (int i = lane; i < dim; i += 64) out[row * dim + i] = xr[i] / den;
+    for (int i = lane; i < dim; i += 64) {
+        const float v = xr[i] / den;
+        if (OUT16) out16[row * dim + i] = bf16_rne(v);
+        else if (tr_cols > 0) out[(int64_t)i * tr_cols + row] = v;
+        else out[row * dim + i] = v;
+    }
+}
+
+// bf16 rows widened back to fp32 (icrec_index_export)
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = __uint_as_float((unsigned)in[i] << 16);
 }
 
 // ---------------------------------------------------------------- score + select
@@ -86,9 +113,10 @@ __device__ __forceinline__ void merge_queue(u64* list, const u64* queue, int n, 
 // tiles [chunk*tiles_per_chunk, ...) against query tile qtile and keeps, per query, the k best
 // (score, row) seen, then writes them (sorted, as keys) to partial[chunk][query][0..k).
 // EMIT = true additionally stores every score to scores_out[q*N + row] (parity checks only).
-template <class Cfg, bool EMIT>
+// P16: the catalog rows are stored as bfloat16 (ICREC_ROWS_BF16) and widened on their way into LDS.
+template <class Cfg, bool EMIT, bool P16>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
-    const float* __restrict__ P, int64_t N, int K, const float* __restrict__ Qn, int Qpad, int Q, int k,
+    const void* __restrict__ P, int64_t N, int K, const float* __restrict__ Qn, int Qpad, int Q, int k,
     const int32_t* __restrict__ excl_idx, const int32_t* __restrict__ excl_off, uint32_t row_base,
     int n_row_tiles, int tiles_per_chunk, int n_qtiles, u64* __restrict__ partial, float* __restrict__ scores_out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -129,12 +157,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     const int t_begin = chunk * tiles_per_chunk;
     const int t_end = min(n_row_tiles, t_begin + tiles_per_chunk);
     int round = 0;
-    TileRegs<Cfg> pre;
+    TileRegs<Cfg, P16> pre;
     f32x16 acc[Cfg::TM][Cfg::TN];
 
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int64_t row0 = (int64_t)tile * Cfg::BM;
-        tile_gemm<Cfg>(acc, P, row0, N, Qn, q0, Qpad, K, As, Bs, pre, false);
+        tile_gemm<Cfg, P16>(acc, P, row0, N, Qn, q0, Qpad, K, As, Bs, pre, false);
 
         if (EMIT) {
 #pragma unroll
@@ -264,10 +292,186 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     }
 }
 
+// ---------------------------------------------------------------- small-batch streaming search
+// For Q <= 8 queries the MFMA kernel above spends 4-32x its useful work on padding columns (its
+// narrowest tile is 32 queries wide) and becomes MFMA-bound long before HBM.  This kernel is the
+// HBM-bound form (SURVEY §8d "K8a"): one thread per catalog row.  A block streams tiles of 256 rows
+// through LDS in 128-byte slabs (coalesced 16-B global loads, next slab in flight under the current
+// one's FMAs); each thread walks ITS row of the slab out of LDS and runs one fp32 fmaf chain per
+// query, k ascending from 0 — the very chain the f32 MFMA computes, so scores stay bit-identical to
+// the oracle.  Query values are block-uniform (scalar loads).  Selection: the block's first tile ranks
+// its 256 keys per query by counting (no merges); later tiles offer only keys above the running k-th
+// best into a 256-slot LDS queue that merge_queue folds into the sorted list.
+constexpr int ST_ROWS = 256, ST_LDB = 144;  // LDS row stride 144 B: conflict-free 16-B reads at one row per lane
+
+template <int NQ>
+struct StreamSmem {
+    static __host__ __device__ size_t bytes(int k) {
+        return (size_t)ST_ROWS * ST_LDB + 64 /*thr*/ + 64 /*cnt*/ + (size_t)((NQ * k + 1) & ~1) * 8 + (size_t)NQ * ST_ROWS * 8;
+    }
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+// acc[j] = fmaf(q[j], p, acc[j]) for the NQ queries of one k; pairs of queries share one packed FMA
+// (v_pk_fma_f32: two independent IEEE fmas, so each chain is unchanged).
+template <int NQ>
+__device__ __forceinline__ void stream_fma(float (&acc)[NQ], const float* __restrict__ q, float p) {
+    if (NQ == 1) {
+        acc[0] = fmaf(q[0], p, acc[0]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NQ; j += 2) {
+            const v2f a = {acc[j], acc[j + 1]}, qq = {q[j], q[j + 1]}, pp = {p, p};
+            const v2f r = __builtin_elementwise_fma(qq, pp, a);
+            acc[j] = r.x;
+            acc[j + 1] = r.y;
+        }
+    }
+}
+
+// 128-B slab `slab` of the 256 rows of tile `tile` -> 8 x 16 B per thread (rows clamped to the last valid row)
+__device__ __forceinline__ void stream_load_slab(v4f (&pre)[8], const char* __restrict__ Pb, int64_t N, int row_bytes,
+                                                 int tile, int slab, int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + ST_ROWS * i;
+        int64_t row = (int64_t)tile * ST_ROWS + (id >> 3);
+        row = row < N ? row : N - 1;
+        pre[i] = *reinterpret_cast<const v4f*>(Pb + row * row_bytes + slab * 128 + (id & 7) * 16);
+    }
+}
+
+template <int NQ, bool P16>
+__global__ __launch_bounds__(ST_ROWS, 2) void stream_search_kernel(
+    const void* __restrict__ P, int64_t N, int K, const float* __restrict__ Qn /* [K][NQ], zero-padded columns */, int Q,
+    int k, const int32_t* __restrict__ excl_idx, const int32_t* __restrict__ excl_off, uint32_t row_base, int n_row_tiles,
+    int tiles_per_chunk, u64* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* rows_s = smem_raw;
+    u64* thr = reinterpret_cast<u64*>(smem_raw + ST_ROWS * ST_LDB);
+    int* cnt = reinterpret_cast<int*>(thr + 8);
+    u64* list = reinterpret_cast<u64*>(cnt + 16);
+    u64* queue = list + (size_t)((NQ * k + 1) & ~1);  // 16-B aligned: the cold path reads it two keys at a time
+
+    constexpr int EPW = P16 ? 2 : 1;             // elements per 32-bit word
+    constexpr int SLAB_ELEMS = 32 * EPW;         // 128 B of one row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = xcd_remap(blockIdx.x, gridDim.x);
+    const int row_bytes = K * (P16 ? 2 : 4);
+    const int nslab = K / SLAB_ELEMS;
+    const char* Pb = static_cast<const char*>(P);
+
+    if (tid < NQ) { thr[tid] = tid < Q ? 0ull : ~0ull; cnt[tid] = 0; }
+    for (int i = tid; i < NQ * k; i += ST_ROWS) list[i] = 0ull;
+
+    u64 mythr[NQ];
+    int ex_lo[NQ], ex_hi[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        mythr[j] = j < Q ? 0ull : ~0ull;
+        ex_lo[j] = ex_hi[j] = 0;
+        if (excl_off != nullptr && j < Q) { ex_lo[j] = excl_off[j]; ex_hi[j] = excl_off[j + 1]; }
+    }
+
+    const int t_begin = chunk * tiles_per_chunk;
+    const int t_end = min(n_row_tiles, t_begin + tiles_per_chunk);
+    v4f pre[8];  // native vectors: HIP's float4 struct copies become memcpys that pin the array in scratch
+    stream_load_slab(pre, Pb, N, row_bytes, min(t_begin, n_row_tiles - 1), 0, tid);
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        float acc[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) acc[j] = 0.0f;
+        for (int s = 0; s < nslab; ++s) {
+            __syncthreads();  // the previous slab has been consumed (also covers the list/thr initialisation)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = tid + ST_ROWS * i;
+                *reinterpret_cast<v4f*>(rows_s + (id >> 3) * ST_LDB + (id & 7) * 16) = pre[i];
+            }
+            __syncthreads();
+            {   // next slab (of this tile or the first of the next one) goes in flight under this slab's FMAs;
+                // unconditional — the block's very last iteration re-loads its own slab — so `pre` stays in registers
+                const bool wrap = s + 1 == nslab;
+                const int nt = wrap ? min(tile + 1, t_end - 1) : tile, ns = wrap ? 0 : s + 1;
+                stream_load_slab(pre, Pb, N, row_bytes, nt, ns, tid);
+            }
+            const char* my = rows_s + tid * ST_LDB;
+            const float* qs = Qn + (size_t)s * SLAB_ELEMS * NQ;  // k-major: the NQ values of one k are adjacent
+            // NQ (x2 for bf16 rows) x 8 scalar query values per 16-B piece: unroll only as far as SGPRs allow
+#pragma unroll(NQ >= 8 ? 1 : NQ >= 4 ? 2 : 8)
+            for (int c = 0; c < 8; ++c) {
+                const v4f w = *reinterpret_cast<const v4f*>(my + c * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (P16) {
+                        const unsigned u = __float_as_uint(w[e]);
+                        const int kk = c * 8 + e * 2;
+                        stream_fma<NQ>(acc, qs + kk * NQ, __uint_as_float(u << 16));
+                        stream_fma<NQ>(acc, qs + (kk + 1) * NQ, __uint_as_float(u & 0xFFFF0000u));
+                    } else {
+                        stream_fma<NQ>(acc, qs + (c * 4 + e) * NQ, w[e]);
+                    }
+                }
+            }
+        }
+
+        // ---- selection for this tile's 256 scores per query
+        const int64_t row = (int64_t)tile * ST_ROWS + tid;
+        u64 key[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const u64 kx = make_key(acc[j] + 0.0f, row_base + (uint32_t)row);
+            bool take = row < N && mythr[j] != ~0ull && kx > mythr[j];
+            if (take && ex_hi[j] > ex_lo[j]) take = !excluded(excl_idx, ex_lo[j], ex_hi[j], (int)row);
+            key[j] = take ? kx : 0ull;
+        }
+        if (tile == t_begin) {
+            // cold: rank every key among the tile's 256 by counting; rank r < k goes straight to list[r]
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) queue[j * ST_ROWS + tid] = key[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (j < Q) {  // uniform
+                    int r = 0;
+                    const u64* qj = queue + j * ST_ROWS;
+                    for (int i = 0; i < ST_ROWS; i += 2) {
+                        const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(qj + i);  // LDS broadcast
+                        r += (two.x > key[j]) + (two.y > key[j]);
+                    }
+                    if (key[j] != 0ull && r < k) list[j * k + r] = key[j];
+                }
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                if (key[j] != 0ull) queue[j * ST_ROWS + atomicAdd(&cnt[j], 1)] = key[j];  // <= 256 offers per tile
+            __syncthreads();
+            for (int j = wave; j < NQ; j += ST_ROWS / 64) {
+                const int c = cnt[j];
+                for (int off = 0; off < c; off += 64)
+                    merge_queue(list + (size_t)j * k, queue + j * ST_ROWS + off, min(64, c - off), k, lane);
+                if (lane == 0) cnt[j] = 0;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            if (mythr[j] != ~0ull) mythr[j] = list[(size_t)j * k + k - 1];
+    }
+
+    __syncthreads();
+    for (int i = tid; i < NQ * k; i += ST_ROWS) partial[(size_t)chunk * NQ * k + i] = list[i];
+}
+
 // ---------------------------------------------------------------- k-way merge of sorted lists
 // keys: [n_lists][q_stride][k] sorted descending per (list, query); one wavefront per query
-// runs a tournament: every lane holds the heads of up to 4 lists.
-constexpr int MERGE_LPL = 4;  // lists per lane => at most 256 lists
+// runs a tournament: every lane holds the heads of up to MERGE_LPL lists.
+constexpr int MERGE_MAX_LISTS = 1024;
+template <int MERGE_LPL>  // lists per lane: 4 (<= 256 lists) or 16 (<= 1024)
 __global__ __launch_bounds__(256) void merge_kernel(const u64* __restrict__ keys, int n_lists, int q_stride, int Q,
                                                     int k, int64_t* __restrict__ out_idx,
                                                     float* __restrict__ out_score, u64* __restrict__ out_keys) {
@@ -309,7 +513,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const u64* __restrict__ keys
 
 // ---------------------------------------------------------------- host side
 struct Index {
-    float* rows = nullptr;  // normalised [n_rows, dim]
+    void* rows = nullptr;  // normalised [n_rows, dim], fp32 or bf16 bits
+    int storage = ICREC_ROWS_F32;
     int64_t n_rows = 0;
     int dim = 0;
     int64_t row_offset = 0;
@@ -328,31 +533,70 @@ struct Plan {
     size_t ws_q, ws_partial, ws_total;
 };
 
-static Plan make_plan(const Index* ix, int Q, int k) {
+// Largest batch the streaming kernel takes (ICREC_STREAM_MAX_Q=0 disables it; tuning/diagnostic knob).
+static int stream_max_q() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ICREC_STREAM_MAX_Q");
+        v = e ? atoi(e) : 8;
+        if (v > 8) v = 8;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+
+static Plan make_plan(const Index* ix, int Q, int k, bool allow_stream) {
     Plan p;
-    if (Q > 64 && k <= 32) { p.variant = 0; p.BM = CfgBig::BM; p.BN = CfgBig::BN; p.smem = SearchSmem<CfgBig>::bytes(k); }
-    else if (Q > 32 && k <= 64) { p.variant = 1; p.BM = CfgMid::BM; p.BN = CfgMid::BN; p.smem = SearchSmem<CfgMid>::bytes(k); }
-    else { p.variant = 2; p.BM = CfgSmall::BM; p.BN = CfgSmall::BN; p.smem = SearchSmem<CfgSmall>::bytes(k); }
-    p.n_qtiles = (Q + p.BN - 1) / p.BN;
-    p.Qpad = p.n_qtiles * p.BN;
-    p.n_row_tiles = (int)((ix->n_rows + p.BM - 1) / p.BM);
-    // one full wave of resident blocks (2 per CU fit by LDS/VGPR), at most 256 chunks (merge_kernel limit)
-    int want_chunks = (2 * ix->n_cu) / p.n_qtiles;
-    if (want_chunks < 1) want_chunks = 1;
-    if (want_chunks > 256) want_chunks = 256;
-    if (want_chunks > p.n_row_tiles) want_chunks = p.n_row_tiles;
-    p.tiles_per_chunk = (p.n_row_tiles + want_chunks - 1) / want_chunks;
-    p.n_chunks = (p.n_row_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    if (allow_stream && Q <= stream_max_q()) {
+        // variant 3: stream_search_kernel<NQ>, one block per chunk of 256-row tiles, no query tiling
+        const int nq = Q <= 1 ? 1 : Q <= 2 ? 2 : Q <= 4 ? 4 : 8;
+        p.variant = 3; p.BM = ST_ROWS; p.BN = nq;
+        p.smem = nq == 1 ? StreamSmem<1>::bytes(k) : nq == 2 ? StreamSmem<2>::bytes(k) : nq == 4 ? StreamSmem<4>::bytes(k)
+                                                                                                 : StreamSmem<8>::bytes(k);
+        p.n_qtiles = 1;
+        p.Qpad = nq;
+        p.n_row_tiles = (int)((ix->n_rows + p.BM - 1) / p.BM);
+        int want_chunks = 3 * ix->n_cu;  // ~3 blocks per CU are resident (LDS)
+        if (want_chunks > MERGE_MAX_LISTS) want_chunks = MERGE_MAX_LISTS;
+        if (want_chunks > p.n_row_tiles) want_chunks = p.n_row_tiles;
+        p.tiles_per_chunk = (p.n_row_tiles + want_chunks - 1) / want_chunks;
+        p.n_chunks = (p.n_row_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    } else {
+        if (Q > 64 && k <= 32) { p.variant = 0; p.BM = CfgBig::BM; p.BN = CfgBig::BN; p.smem = SearchSmem<CfgBig>::bytes(k); }
+        else if (Q > 32 && k <= 64) { p.variant = 1; p.BM = CfgMid::BM; p.BN = CfgMid::BN; p.smem = SearchSmem<CfgMid>::bytes(k); }
+        else { p.variant = 2; p.BM = CfgSmall::BM; p.BN = CfgSmall::BN; p.smem = SearchSmem<CfgSmall>::bytes(k); }
+        p.n_qtiles = (Q + p.BN - 1) / p.BN;
+        p.Qpad = p.n_qtiles * p.BN;
+        p.n_row_tiles = (int)((ix->n_rows + p.BM - 1) / p.BM);
+        // one full wave of resident blocks (2 per CU fit by LDS/VGPR), at most 256 chunks
+        int want_chunks = (2 * ix->n_cu) / p.n_qtiles;
+        if (want_chunks < 1) want_chunks = 1;
+        if (want_chunks > 256) want_chunks = 256;
+        if (want_chunks > p.n_row_tiles) want_chunks = p.n_row_tiles;
+        p.tiles_per_chunk = (p.n_row_tiles + want_chunks - 1) / want_chunks;
+        p.n_chunks = (p.n_row_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    }
     p.ws_q = ((size_t)p.Qpad * ix->dim * 4 + 255) & ~(size_t)255;
     p.ws_partial = ((size_t)p.n_chunks * p.Qpad * k * 8 + 255) & ~(size_t)255;
     p.ws_total = p.ws_q + p.ws_partial;
     return p;
 }
 
-template <class Cfg, bool EMIT>
+template <int NQ, bool P16>
+static int launch_stream(const Index* ix, const Plan& p, const float* qn, int Q, int k, const int32_t* ei,
+                         const int32_t* eo, u64* partial, hipStream_t st) {
+    ScopedTimer tm(T_SEARCH_KERNEL, st);
+    hipLaunchKernelGGL((stream_search_kernel<NQ, P16>), dim3(p.n_chunks), dim3(ST_ROWS), p.smem, st, (const void*)ix->rows,
+                       ix->n_rows, ix->dim, qn, Q, k, ei, eo, (uint32_t)ix->row_offset, p.n_row_tiles, p.tiles_per_chunk,
+                       partial);
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
+}
+
+template <class Cfg, bool EMIT, bool P16>
 static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q, int k, const int32_t* ei,
                          const int32_t* eo, u64* partial, float* scores_out, hipStream_t st) {
-    auto kern = search_kernel<Cfg, EMIT>;
+    auto kern = search_kernel<Cfg, EMIT, P16>;
     static bool attr_set = false;
     if (!attr_set) {
         ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -362,7 +606,7 @@ static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q,
     const int grid = p.n_chunks * p.n_qtiles;
     {
         ScopedTimer tm(T_SEARCH_KERNEL, st);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), p.smem, st, ix->rows, ix->n_rows, ix->dim, qn, p.Qpad,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), p.smem, st, (const void*)ix->rows, ix->n_rows, ix->dim, qn, p.Qpad,
                            Q, k, ei, eo, (uint32_t)ix->row_offset, p.n_row_tiles, p.tiles_per_chunk, p.n_qtiles,
                            partial, scores_out);
     }
@@ -376,7 +620,7 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     ICREC_REQUIRE(Q >= 1, "icrec_search: n_queries must be >= 1 (got %d)", Q);
     ICREC_REQUIRE(k >= 1 && k <= ICREC_MAX_K, "icrec_search: k must be in [1, %d] (got %d)", ICREC_MAX_K, k);
     ICREC_REQUIRE((ei == nullptr) == (eo == nullptr), "icrec_search: excl_idx and excl_off must both be set or both NULL");
-    const Plan p = make_plan(ix, Q, k);
+    const Plan p = make_plan(ix, Q, k, scores_out == nullptr);
     if (ws_bytes < p.ws_total || ws == nullptr) {
         set_error("icrec_search: workspace too small (%zu < %zu)", ws_bytes, p.ws_total);
         return ICREC_ENOMEM;
@@ -385,22 +629,31 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     ScopedTimer whole(T_SEARCH, st);
     float* qn = reinterpret_cast<float*>(ws);
     u64* partial = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + p.ws_q);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((p.Qpad + 3) / 4), dim3(256), 0, st, q, qn, (int64_t)Q,
-                       (int64_t)p.Qpad, ix->dim, 1e-12f);
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((p.Qpad + 3) / 4), dim3(256), 0, st, q, (void*)qn, (int64_t)Q,
+                       (int64_t)p.Qpad, ix->dim, 1e-12f, p.variant == 3 ? p.Qpad : 0);
     int rc;
-    if (scores_out) {
-        rc = p.variant == 0 ? launch_search<CfgBig, true>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
-           : p.variant == 1 ? launch_search<CfgMid, true>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
-                            : launch_search<CfgSmall, true>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st);
-    } else {
-        rc = p.variant == 0 ? launch_search<CfgBig, false>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
-           : p.variant == 1 ? launch_search<CfgMid, false>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)
-                            : launch_search<CfgSmall, false>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st);
-    }
+#define ICREC_SEARCH_DISPATCH(EMIT, P16)                                                                            \
+    (p.variant == 0   ? launch_search<CfgBig, EMIT, P16>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)          \
+     : p.variant == 1 ? launch_search<CfgMid, EMIT, P16>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)          \
+                      : launch_search<CfgSmall, EMIT, P16>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st))
+    if (p.variant == 3) {
+        const bool h = ix->storage == ICREC_ROWS_BF16;
+#define ICREC_STREAM_DISPATCH(NQ) \
+    (h ? launch_stream<NQ, true>(ix, p, qn, Q, k, ei, eo, partial, st) : launch_stream<NQ, false>(ix, p, qn, Q, k, ei, eo, partial, st))
+        rc = p.BN == 1 ? ICREC_STREAM_DISPATCH(1) : p.BN == 2 ? ICREC_STREAM_DISPATCH(2) : p.BN == 4 ? ICREC_STREAM_DISPATCH(4)
+                                                                                                   : ICREC_STREAM_DISPATCH(8);
+#undef ICREC_STREAM_DISPATCH
+    } else if (ix->storage == ICREC_ROWS_BF16) rc = scores_out ? ICREC_SEARCH_DISPATCH(true, true) : ICREC_SEARCH_DISPATCH(false, true);
+    else rc = scores_out ? ICREC_SEARCH_DISPATCH(true, false) : ICREC_SEARCH_DISPATCH(false, false);
+#undef ICREC_SEARCH_DISPATCH
     if (rc != ICREC_OK) return rc;
     if (out_idx || out_keys) {
-        hipLaunchKernelGGL(merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k, out_idx,
-                           out_score, out_keys);
+        if (p.n_chunks <= 256)
+            hipLaunchKernelGGL(merge_kernel<4>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k,
+                               out_idx, out_score, out_keys);
+        else
+            hipLaunchKernelGGL(merge_kernel<16>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k,
+                               out_idx, out_score, out_keys);
         ICREC_HIP(hipGetLastError());
     }
     return ICREC_OK;
@@ -412,12 +665,14 @@ using namespace icrec;
 
 extern "C" {
 
-int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim, int64_t row_offset, int device,
-                       icrec_index** out) {
+int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, int64_t row_offset, int device,
+                          int32_t storage, icrec_index** out) {
     ICREC_REQUIRE(rows_dev && out, "icrec_index_create: NULL argument");
     ICREC_REQUIRE(n_rows >= 1, "icrec_index_create: n_rows must be >= 1");
     ICREC_REQUIRE(dim >= BK && dim % BK == 0 && dim <= 4096, "icrec_index_create: dim must be a multiple of %d (got %d)", BK, dim);
     ICREC_REQUIRE(row_offset >= 0 && row_offset + n_rows < 0xFFFFFFFFll, "icrec_index_create: row_offset + n_rows must be < 2^32-1");
+    ICREC_REQUIRE(storage == ICREC_ROWS_F32 || storage == ICREC_ROWS_BF16,
+                  "icrec_index_create: storage must be ICREC_ROWS_F32 (0) or ICREC_ROWS_BF16 (1), got %d", storage);
     ICREC_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     ICREC_HIP(hipGetDeviceProperties(&prop, device));
@@ -426,21 +681,32 @@ int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim, int64
         return ICREC_ENODEV;
     }
     Index* ix = new Index();
-    ix->n_rows = n_rows; ix->dim = dim; ix->row_offset = row_offset; ix->device = device;
+    ix->n_rows = n_rows; ix->dim = dim; ix->row_offset = row_offset; ix->device = device; ix->storage = storage;
     ix->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipMalloc(&ix->rows, (size_t)n_rows * dim * sizeof(float));
+    const size_t bytes = (size_t)n_rows * dim * (storage == ICREC_ROWS_BF16 ? 2 : 4);
+    hipError_t e = hipMalloc(&ix->rows, bytes);
     if (e != hipSuccess) {
         delete ix;
-        set_error("icrec_index_create: hipMalloc of %zu bytes failed: %s", (size_t)n_rows * dim * 4, hipGetErrorString(e));
+        set_error("icrec_index_create: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
         return ICREC_ENOMEM;
     }
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, 0, rows_dev, ix->rows,
-                       n_rows, n_rows, dim, 1e-12f);
+    const dim3 grid((unsigned)((n_rows + 3) / 4));
+    if (storage == ICREC_ROWS_BF16)
+        hipLaunchKernelGGL(normalize_rows_kernel<true>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
+    else
+        hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
     ICREC_HIP(hipGetLastError());
     ICREC_HIP(hipStreamSynchronize(0));
     *out = reinterpret_cast<icrec_index*>(ix);
     return ICREC_OK;
 }
+
+int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim, int64_t row_offset, int device,
+                       icrec_index** out) {
+    return icrec_index_create_ex(rows_dev, n_rows, dim, row_offset, device, ICREC_ROWS_F32, out);
+}
+
+int32_t icrec_index_storage(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->storage : -1; }
 
 int icrec_index_destroy(icrec_index* h) {
     Index* ix = reinterpret_cast<Index*>(h);
@@ -456,15 +722,23 @@ int64_t icrec_index_rows(const icrec_index* h) { return h ? reinterpret_cast<con
 int icrec_index_export(const icrec_index* h, float* rows_dev, void* stream) {
     const Index* ix = reinterpret_cast<const Index*>(h);
     ICREC_REQUIRE(ix && rows_dev, "icrec_index_export: NULL argument");
-    ICREC_HIP(hipMemcpyAsync(rows_dev, ix->rows, (size_t)ix->n_rows * ix->dim * 4, hipMemcpyDeviceToDevice,
-                             (hipStream_t)stream));
+    const int64_t n = ix->n_rows * ix->dim;
+    if (ix->storage == ICREC_ROWS_BF16) {
+        ICREC_HIP(hipSetDevice(ix->device));
+        hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const uint16_t*>(ix->rows), rows_dev, n);
+        ICREC_HIP(hipGetLastError());
+    } else {
+        ICREC_HIP(hipMemcpyAsync(rows_dev, ix->rows, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     return ICREC_OK;
 }
 
 size_t icrec_search_workspace_bytes(const icrec_index* h, int32_t n_queries, int32_t k) {
     const Index* ix = reinterpret_cast<const Index*>(h);
     if (!ix || n_queries < 1 || k < 1 || k > ICREC_MAX_K) return 0;
-    return make_plan(ix, n_queries, k).ws_total;
+    const size_t a = make_plan(ix, n_queries, k, false).ws_total, b = make_plan(ix, n_queries, k, true).ws_total;
+    return a > b ? a : b;
 }
 
 int icrec_search(icrec_index* h, const float* q_dev, int32_t n_queries, int32_t k, const int32_t* excl_idx_dev,
@@ -492,12 +766,17 @@ int icrec_scores(icrec_index* h, const float* q_dev, int32_t n_queries, float* o
 int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists, int32_t n_queries, int32_t k, int64_t* out_idx_dev,
                      float* out_score_dev, int device, void* stream) {
     ICREC_REQUIRE(keys_dev && out_idx_dev && out_score_dev, "icrec_merge_topk: NULL argument");
-    ICREC_REQUIRE(n_lists >= 1 && n_lists <= 64 * MERGE_LPL, "icrec_merge_topk: n_lists must be in [1, %d]", 64 * MERGE_LPL);
+    ICREC_REQUIRE(n_lists >= 1 && n_lists <= MERGE_MAX_LISTS, "icrec_merge_topk: n_lists must be in [1, %d]", MERGE_MAX_LISTS);
     ICREC_REQUIRE(n_queries >= 1 && k >= 1 && k <= ICREC_MAX_K, "icrec_merge_topk: bad n_queries/k");
     ICREC_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL(merge_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const u64*>(keys_dev), n_lists, n_queries, n_queries, k, out_idx_dev,
-                       out_score_dev, (u64*)nullptr);
+    if (n_lists <= 256)
+        hipLaunchKernelGGL(merge_kernel<4>, dim3((n_queries + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const u64*>(keys_dev), n_lists, n_queries, n_queries, k, out_idx_dev,
+                           out_score_dev, (u64*)nullptr);
+    else
+        hipLaunchKernelGGL(merge_kernel<16>, dim3((n_queries + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const u64*>(keys_dev), n_lists, n_queries, n_queries, k, out_idx_dev,
+                           out_score_dev, (u64*)nullptr);
     ICREC_HIP(hipGetLastError());
     return ICREC_OK;
 }
@@ -506,8 +785,8 @@ int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n_rows, int
                          void* stream) {
     ICREC_REQUIRE(x_dev && out_dev && n_rows >= 1 && dim >= 1, "icrec_normalize_rows: bad argument");
     ICREC_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       x_dev, out_dev, n_rows, n_rows, dim, eps);
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x_dev, (void*)out_dev, n_rows, n_rows, dim, eps);
     ICREC_HIP(hipGetLastError());
     return ICREC_OK;
 }

@@ -45,10 +45,20 @@ def exclusion_csr(exclude: Optional[Sequence[Iterable[int]]], n_queries: int, de
     return idx, torch.from_numpy(off).to(device)
 
 
-class DeviceIndex:
-    """A row shard of the product-embedding matrix, normalised and resident on one GPU."""
+ROW_STORAGE = {"f32": 0, "bf16": 1}  # ICREC_ROWS_* in include/icrec.h
 
-    def __init__(self, embeddings, device: str | torch.device = "cuda:0", row_offset: int = 0):
+
+class DeviceIndex:
+    """A row shard of the product-embedding matrix, normalised and resident on one GPU.
+
+    storage="bf16" keeps the normalised rows as bfloat16 (half the HBM; BASELINE config 5's 10M-row
+    catalog); the arithmetic stays the exact fp32 fmaf chain over the widened values."""
+
+    def __init__(self, embeddings, device: str | torch.device = "cuda:0", row_offset: int = 0,
+                 storage: str = "f32"):
+        if storage not in ROW_STORAGE:
+            raise ValueError(f"storage must be one of {sorted(ROW_STORAGE)}, got {storage!r}")
+        self.storage = storage
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _native.IcrecError("DeviceIndex needs a CUDA/HIP device; there is no CPU fallback")
@@ -63,8 +73,8 @@ class DeviceIndex:
         self.row_offset = int(row_offset)
         h = C.c_void_p()
         torch.cuda.synchronize(self.device)
-        _native.check(L.icrec_index_create(_ptr(rows), self.n_rows, self.dim, self.row_offset, self.device.index,
-                                           C.byref(h)), "icrec_index_create")
+        _native.check(L.icrec_index_create_ex(_ptr(rows), self.n_rows, self.dim, self.row_offset, self.device.index,
+                                              ROW_STORAGE[storage], C.byref(h)), "icrec_index_create_ex")
         self._h = h
         self._ws: Optional[torch.Tensor] = None
 

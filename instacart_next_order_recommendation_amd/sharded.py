@@ -41,10 +41,10 @@ class ShardBackend(Protocol):
 class HipShardBackend:
     """The product backend: libicrec kernels on this rank's GPU."""
 
-    def __init__(self, shard_rows, row_offset: int, device):
+    def __init__(self, shard_rows, row_offset: int, device, storage: str = "f32"):
         from .search import DeviceIndex
 
-        self.index = DeviceIndex(shard_rows, device, row_offset=row_offset)
+        self.index = DeviceIndex(shard_rows, device, row_offset=row_offset, storage=storage)
 
     def search_partial(self, q, k, exclude):
         return self.index.search_partial(q, k, exclude)

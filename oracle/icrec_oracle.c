@@ -361,6 +361,39 @@ ORACLE_API void icrec_oracle_search(const float* q, const float* P, int Q, int64
     free(qh); free(ph); free(sc);
 }
 
+/* ICREC_ROWS_BF16 storage (include/icrec.h): each value rounded to bfloat16, round-to-nearest-even,
+ * returned widened to fp32 (torch's .to(torch.bfloat16).float(); pinned against it in tests/test_oracle.py). */
+ORACLE_API void icrec_oracle_round_bf16(const float* x, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t u;
+        memcpy(&u, x + i, 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        memcpy(out + i, &u, 4);
+    }
+}
+
+/* icrec_oracle_search with the catalog held as bf16: cos_sim's normalisation, THEN the rounding of the
+ * normalised rows, then the same fp32 fmaf chains and the same ranking loop. */
+ORACLE_API void icrec_oracle_search_bf16(const float* q, const float* P, int Q, int64_t N, int d, int k,
+                                         const int32_t* excl_idx, const int32_t* excl_off,
+                                         int64_t row_offset, int64_t* out_idx, float* out_score) {
+    float* qh = (float*)malloc((size_t)Q * d * sizeof(float));
+    float* ph = (float*)malloc((size_t)N * d * sizeof(float));
+    float* sc = (float*)malloc((size_t)Q * N * sizeof(float));
+    icrec_oracle_normalize_rows(q, qh, Q, d, 1e-12f);
+    icrec_oracle_normalize_rows(P, ph, N, d, 1e-12f);
+    icrec_oracle_round_bf16(ph, ph, N * d);
+    icrec_oracle_scores(qh, ph, Q, N, d, sc);
+#pragma omp parallel for schedule(dynamic)
+    for (int qi = 0; qi < Q; ++qi) {
+        const int32_t* ex = excl_idx && excl_off ? excl_idx + excl_off[qi] : NULL;
+        int ne = excl_idx && excl_off ? excl_off[qi + 1] - excl_off[qi] : 0;
+        icrec_oracle_rank(sc + (size_t)qi * N, N, k, ex, ne, row_offset,
+                          out_idx + (size_t)qi * k, out_score + (size_t)qi * k);
+    }
+    free(qh); free(ph); free(sc);
+}
+
 /* Merge per-shard (idx, score) lists [n_lists, Q, k] into the global top-k under
  * the same order; -1 entries are pads.  (Restates "rank the union".) */
 ORACLE_API void icrec_oracle_merge(const int64_t* idx, const float* score, int n_lists, int Q, int k,

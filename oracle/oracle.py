@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         L.icrec_oracle_search.restype = None
         L.icrec_oracle_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.icrec_oracle_search_bf16.restype = None
+        L.icrec_oracle_search_bf16.argtypes = L.icrec_oracle_search.argtypes
+        L.icrec_oracle_round_bf16.restype = None
+        L.icrec_oracle_round_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.icrec_oracle_merge.restype = None
         L.icrec_oracle_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p]
@@ -128,14 +132,24 @@ def _csr(excl, n_queries):
     return np.asarray(flat, np.int32), off
 
 
-def search(q: np.ndarray, P: np.ndarray, k: int, excl=None, row_offset: int = 0):
-    """cos_sim + argsort + exclusion loop.  excl: per-query iterables of LOCAL row numbers."""
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bfloat16 (round to nearest even) -> fp32."""
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().icrec_oracle_round_bf16(_p(x), _p(out), x.size)
+    return out
+
+
+def search(q: np.ndarray, P: np.ndarray, k: int, excl=None, row_offset: int = 0, storage: str = "f32"):
+    """cos_sim + argsort + exclusion loop.  excl: per-query iterables of LOCAL row numbers.
+    storage="bf16": the normalised catalog rows are rounded to bfloat16 first (ICREC_ROWS_BF16)."""
     q, P = _f32(q), _f32(P)
     Q = q.shape[0]
     ei, eo = _csr(excl, Q)
     idx = np.empty((Q, k), np.int64)
     sc = np.empty((Q, k), np.float32)
-    lib().icrec_oracle_search(_p(q), _p(P), Q, P.shape[0], q.shape[1], k, _p(ei), _p(eo), row_offset,
+    fn = {"f32": lib().icrec_oracle_search, "bf16": lib().icrec_oracle_search_bf16}[storage]
+    fn(_p(q), _p(P), Q, P.shape[0], q.shape[1], k, _p(ei), _p(eo), row_offset,
                               _p(idx), _p(sc))
     return idx, sc
 

@@ -117,3 +117,27 @@ def test_merge_equals_unsharded(golden_search):
     mi, ms = oracle.merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
     np.testing.assert_array_equal(mi, whole_i)
     np.testing.assert_array_equal(ms, whole_s)
+
+
+def test_bf16_rounding_matches_torch():
+    """icrec_oracle_round_bf16 is torch's fp32 -> bfloat16 (round-to-nearest-even), incl. exact ties."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4096).astype(np.float32) * 0.05,
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, -1.00390625, 3.0e-39, 65504.0], np.float32)])
+    want = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(oracle.round_bf16(x).view(np.uint32), want.view(np.uint32))
+
+
+def test_bf16_storage_search_is_search_on_rounded_rows(golden_search):
+    """storage="bf16" == the plain oracle run on rows that are already normalised-and-rounded, up to the
+    second normalisation cos_sim would apply (which the bf16 path deliberately does not)."""
+    g = golden_search
+    q, P, k = g["q"], g["P"], int(g["k"])
+    idx, sc = oracle.search(q, P, k, storage="bf16")
+    rows = oracle.round_bf16(oracle.normalize_rows(P))
+    s = oracle.scores(oracle.normalize_rows(q), rows)
+    order = np.lexsort((np.arange(s.shape[1])[None, :].repeat(s.shape[0], 0), -s), axis=1)[:, :k]
+    np.testing.assert_array_equal(idx, order)
+    np.testing.assert_array_equal(sc, np.take_along_axis(s, order, axis=1))

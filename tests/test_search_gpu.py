@@ -183,3 +183,110 @@ def test_large_batch_properties(torch_cuda):
     # idempotence: same call, same bits
     idx2, sc2 = ix.search(q, 20)
     assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+
+
+# ---------------------------------------------------------------- bf16 row storage (BASELINE config 5)
+def test_bf16_index_holds_rounded_rows(torch_cuda, golden_search):
+    """ICREC_ROWS_BF16: normalise in fp32, then round to bfloat16 (RNE) — bit-identical to the oracle
+    and to torch's own fp32 -> bf16 conversion of the same normalised rows."""
+    torch = torch_cuda
+    o = _oracle()
+    ix = _search_mod().DeviceIndex(golden_search["P"], storage="bf16")
+    got = ix.export().cpu().numpy()
+    want = o.round_bf16(o.normalize_rows(golden_search["P"]))
+    np.testing.assert_array_equal(got, want)
+    t = torch.from_numpy(o.normalize_rows(golden_search["P"])).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(got, t)
+
+
+@pytest.mark.parametrize("nq,k,n", [(1, 20, 1024), (3, 7, 257), (40, 20, 1000), (70, 50, 3000), (130, 20, 5000),
+                                      (200, 100, 2049)])
+def test_bf16_rows_search_vs_oracle(torch_cuda, nq, k, n):
+    """bf16 storage changes the stored rows only: indices AND scores stay bit-exact against the oracle
+    run on the same rounded rows (all three tile variants, random exclusions)."""
+    rng = np.random.default_rng(nq * 977 + k)
+    P = rng.standard_normal((n, 384)).astype(np.float32)
+    q = rng.standard_normal((nq, 384)).astype(np.float32)
+    excl = [rng.choice(n, size=rng.integers(0, min(n, 40)), replace=False).tolist() for _ in range(nq)]
+    want_i, want_s = _oracle().search(q, P, k, excl, storage="bf16")
+    ix = _search_mod().DeviceIndex(P, storage="bf16")
+    idx, sc = ix.search(q, k, excl)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want_s)
+    # the full score matrix too
+    o = _oracle()
+    full = ix.scores(q).cpu().numpy()
+    np.testing.assert_array_equal(full, o.scores(o.normalize_rows(q), o.round_bf16(o.normalize_rows(P))))
+    # and it is a faithful approximation of the fp32 catalog: cosine within bf16 rounding of the rows
+    ref = o.scores(o.normalize_rows(q), o.normalize_rows(P))
+    assert np.abs(full - ref).max() < 2e-3
+
+
+def test_bf16_rows_full_catalog_sample(torch_cuda):
+    """49,688 rows x 1,024 queries in bf16 storage: sorted, unique, and a sample of queries exact vs the oracle."""
+    syn = _syn()
+    P = syn.synthetic_embeddings(49688, 384, seed=1)
+    q = syn.synthetic_embeddings(1024, 384, seed=3)
+    ix = _search_mod().DeviceIndex(P, storage="bf16")
+    idx, sc = ix.search(q, 20)
+    idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+    assert (np.diff(sc_h, axis=1) <= 0).all() and all(len(set(r.tolist())) == 20 for r in idx_h)
+    sample = [0, 5, 512, 1023]
+    wi, ws = _oracle().search(q[sample], P, 20, storage="bf16")
+    np.testing.assert_array_equal(idx_h[sample], wi)
+    np.testing.assert_array_equal(sc_h[sample], ws)
+    with pytest.raises(ValueError):
+        _search_mod().DeviceIndex(P[:4], storage="fp8")
+
+
+# ---------------------------------------------------------------- small-batch streaming kernel (Q <= 8)
+@pytest.fixture(scope="module")
+def big_clustered():
+    """400,000 clustered rows + 8 queries (numpy generator: the repo's counter-based one takes a minute at this size)."""
+    rng = np.random.default_rng(11)
+    centres = rng.standard_normal((200, 384)).astype(np.float32)
+    P = centres[rng.integers(0, 200, 400_000)] + 0.35 * rng.standard_normal((400_000, 384), dtype=np.float32)
+    q = centres[rng.integers(0, 200, 8)] + 0.35 * rng.standard_normal((8, 384), dtype=np.float32)
+    return P, q
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("nq,k", [(1, 20), (2, 1), (5, 100), (8, 20)])
+def test_stream_kernel_multi_tile_chunks(torch_cuda, big_clustered, storage, nq, k):
+    """400,000 rows = 1,563 tiles of 256 rows over <= 768 blocks: every block runs its cold first tile
+    (rank by counting) AND warm tiles (threshold + queue + merge), with exclusions that hit the true
+    top of each list.  Bit-exact indices and scores against the oracle."""
+    n = 400_000
+    P, qall = big_clustered
+    q = qall[:nq]
+    o = _oracle()
+    top_i, _ = o.search(q, P, 8, storage=storage)
+    rng = np.random.default_rng(nq + k)
+    excl = [sorted(set(top_i[i, ::2].tolist()) | set(rng.choice(n, 30, replace=False).tolist())) for i in range(nq)]
+    excl[0] = []  # one query without exclusions
+    want_i, want_s = o.search(q, P, k, excl, storage=storage)
+    ix = _search_mod().DeviceIndex(P, storage=storage)
+    idx, sc = ix.search(q, k, excl)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want_s)
+    # shard-local lists + merge agree too (row_offset, > 256 lists through the 16-lists-per-lane merge)
+    keys = ix.search_partial(q, k, excl)
+    idx2, sc2 = _search_mod().merge_topk(keys.unsqueeze(0), k)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), want_i)
+
+
+def test_merge_many_lists(torch_cuda):
+    """icrec_merge_topk with 700 lists (the streaming kernel's chunk count exceeds 256)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    n_lists, Q, k = 700, 3, 20
+    sc = rng.standard_normal((n_lists, Q, k)).astype(np.float32)
+    sc = -np.sort(-sc, axis=2)
+    idx = (np.arange(n_lists)[:, None, None] * 1000 + np.arange(k)[None, None, :] + np.zeros((1, Q, 1), np.int64)).astype(np.int64)
+    u = sc.view(np.uint32).astype(np.uint64)
+    u = np.where(u & 0x80000000, ~u & 0xFFFFFFFF, u | 0x80000000)
+    keys = (u << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - idx.astype(np.uint64))
+    got_i, got_s = _search_mod().merge_topk(torch.from_numpy(keys.view(np.int64)).cuda(), k)
+    want_i, want_s = _oracle().merge(idx, sc)
+    np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(got_s.cpu().numpy(), want_s)

@@ -13,6 +13,7 @@ from instacart_next_order_recommendation_amd.search import DeviceIndex
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, nargs="+", default=[49688, 2_000_000])
+ap.add_argument("--storage", default="f32", choices=["f32", "bf16"])
 ap.add_argument("--queries", type=int, nargs="+", default=[1, 8, 32, 64, 256, 1024])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -24,7 +25,8 @@ for n in args.rows:
     for s in range(0, n, 1 << 18):
         m = min(1 << 18, n - s)
         rows[s:s + m] = centres[torch.randint(0, 200, (m,), device=dev, generator=g)] + 0.35 * torch.randn(m, 384, device=dev, generator=g)
-    ix = DeviceIndex(rows, dev)
+    ix = DeviceIndex(rows, dev, storage=args.storage)
+    esz = 4 if args.storage == "f32" else 2
     del rows
     for q in args.queries:
         qv = centres[torch.randint(0, 200, (q,), device=dev, generator=g)] + 0.35 * torch.randn(q, 384, device=dev, generator=g)
@@ -41,9 +43,9 @@ for n in args.rows:
         t_ms, _ = _native.timing_query(3)
         bn = 128 if q > 64 else (64 if q > 32 else 32)
         passes = -(-q // bn)
-        rec = {"rows": n, "queries": q, "kernel_ms": round(k_ms, 4), "search_call_ms": round(t_ms, 4),
-               "catalog_GBps_once": round(n * 384 * 4 / k_ms / 1e6, 1),
-               "catalog_GBps_per_query_tile_pass": round(passes * n * 384 * 4 / k_ms / 1e6, 1),
+        rec = {"rows": n, "storage": args.storage, "queries": q, "kernel_ms": round(k_ms, 4), "search_call_ms": round(t_ms, 4),
+               "catalog_GBps_once": round(n * 384 * esz / k_ms / 1e6, 1),
+               "catalog_GBps_per_query_tile_pass": round(passes * n * 384 * esz / k_ms / 1e6, 1),
                "TFLOPs_algorithmic": round(2.0 * q * n * 384 / k_ms / 1e9, 2),
                "TFLOPs_issued_padded": round(2.0 * passes * bn * n * 384 / k_ms / 1e9, 2), "qps": round(q / t_ms * 1e3)}
         out.append(rec)
