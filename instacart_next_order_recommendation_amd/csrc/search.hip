@@ -547,7 +547,11 @@ static int stream_max_q() {
 
 static Plan make_plan(const Index* ix, int Q, int k, bool allow_stream) {
     Plan p;
-    if (allow_stream && Q <= stream_max_q()) {
+    // The streaming kernel pays a per-block cold start (rank 256 keys per query by counting) that only amortises
+    // over several tiles: take it for Q <= 2 always, for Q <= 8 once every block has >= 2 tiles (measured at
+    // 49,688 rows, f32: Q=8 67 us streaming vs 44 us MFMA; at 2M rows 0.64 ms vs 0.76 ms).
+    const int64_t st_tiles = (ix->n_rows + ST_ROWS - 1) / ST_ROWS;
+    if (allow_stream && Q <= stream_max_q() && (Q <= 2 || st_tiles >= 2 * 3 * (int64_t)ix->n_cu)) {
         // variant 3: stream_search_kernel<NQ>, one block per chunk of 256-row tiles, no query tiling
         const int nq = Q <= 1 ? 1 : Q <= 2 ? 2 : Q <= 4 ? 4 : 8;
         p.variant = 3; p.BM = ST_ROWS; p.BN = nq;
