@@ -141,7 +141,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
 // Same layers on the f16 matrix cores with 3-term operand splitting (gemm_x3.h).  A and W arrive as
 // f16 hi/lo planes.  EPI 0: out_f32 = acc + bias.  EPI 1: erf-GELU, result written as hi/lo planes
 // (the FFN-down GEMM's A operand) and never as fp32.
-template <class Cfg, int EPI>
+// DEPTH > 1: the small-M (latency-bound) form with DEPTH slabs in flight, see tile_gemm_h_deep.
+template <class Cfg, int EPI, int DEPTH = 1>
 __global__ __launch_bounds__(Cfg::THREADS) void linear_x3_kernel(
     const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int M, int K, const _Float16* __restrict__ Wh,
     const _Float16* __restrict__ Wl, int N, const float* __restrict__ bias, float* __restrict__ out,
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void linear_x3_kernel(
     const int mt = bid / n_tiles_n, nt = bid % n_tiles_n;
     const int64_t m0 = (int64_t)mt * Cfg::BM, n0 = (int64_t)nt * Cfg::BN;
     f32x16 acc0[Cfg::TM][Cfg::TN], acc1[Cfg::TM][Cfg::TN];
-    tile_gemm_h<Cfg>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
+    if (DEPTH > 1) tile_gemm_h_deep<Cfg, DEPTH>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
+    else tile_gemm_h<Cfg>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
         const int64_t col = n0 + (wn * Cfg::TN + j) * 32 + (lane & 31);
@@ -634,6 +636,8 @@ static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T) {
 
 typedef TileCfg<2, 2, 2, 2> GemmBig;  // 128 x 128 output tile, 4 waves
 typedef TileCfg<2, 4, 2, 1> GemmX3;   // 128 x 128 output tile, 8 waves of 64 x 32 (two accumulator sets per tile)
+typedef TileCfg<2, 2, 1, 1> GemmX3Small;  // 64 x 64, 4 waves of one 32 x 32 tile: the small-M form (M <= X3_SMALL_M tokens)
+constexpr int X3_SMALL_M = 512, X3_SMALL_DEPTH = 2;
 
 template <bool GELU>
 static void launch_linear(const float* A, int M, int K, const float* W, int N, const float* bias, float* out,
@@ -647,6 +651,23 @@ template <int EPI>
 static int launch_linear_x3(const _Float16* Ah, const _Float16* Al, int M, int K, const _Float16* Wh,
                             const _Float16* Wl, int N, const float* bias, float* out, _Float16* oh, _Float16* ol,
                             hipStream_t st) {
+    if (M <= X3_SMALL_M) {
+        // Single requests / micro-batches are latency-bound on each wave's MFMA chain and on the slab loop, not
+        // on bandwidth (measured, 99 tokens: 128x128/8 waves 22 us per GEMM, 128x64/4 waves 18 us at any
+        // prefetch depth 1-6, 64x64/4 waves of ONE 32x32 tile 12 us): use the smallest per-wave tile and many
+        // workgroups.  Per-output arithmetic is unchanged, so results are bit-identical to the batch kernel.
+        auto kern = linear_x3_kernel<GemmX3Small, EPI, X3_SMALL_DEPTH>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)SmemH<GemmX3Small>::BYTES));
+            attr_set = true;
+        }
+        const int mt = (M + GemmX3Small::BM - 1) / GemmX3Small::BM, nt = (N + GemmX3Small::BN - 1) / GemmX3Small::BN;
+        hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(GemmX3Small::THREADS), SmemH<GemmX3Small>::BYTES, st, Ah, Al, M, K,
+                           Wh, Wl, N, bias, out, oh, ol, nt);
+        return ICREC_OK;
+    }
     auto kern = linear_x3_kernel<GemmX3, EPI>;
     static bool attr_set = false;
     if (!attr_set) {

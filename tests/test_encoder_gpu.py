@@ -73,6 +73,20 @@ def test_batch_invariance_bitwise(encoder):
         np.testing.assert_array_equal(one[0], full[s])
 
 
+def test_small_and_batch_gemm_paths_agree_bitwise(encoder):
+    """<= 512 tokens take the small-tile (latency) GEMM kernels, larger batches the 128x128 ones: a request
+    must encode to the same bits through either (same per-output MFMA chains)."""
+    from instacart_next_order_recommendation_amd import synthetic as syn
+
+    ids, cu = syn.synthetic_token_batch(24, seed=33, mean_len=100, std_len=40, lo=5, hi=256)
+    assert cu[-1] > 1024
+    full = _encode(encoder, ids, cu)
+    for s in [0, 7, 23]:
+        n = int(cu[s + 1] - cu[s])
+        one = _encode(encoder, ids[cu[s]:cu[s + 1]].copy(), np.array([0, n], np.int32))
+        np.testing.assert_array_equal(one[0], full[s])
+
+
 def test_n_normalize_variants(minilm_weights):
     """n_normalize = 0 (raw mean pool) and 1 match the oracle; 2 is the default path."""
     import torch
