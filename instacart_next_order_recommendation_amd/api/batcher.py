@@ -2,9 +2,9 @@
 
 The reference calls the blocking recommend() inside an `async def` endpoint
 (src/api/routes/recommend.py:89,139-151): one request in flight per process.  Here concurrent
-requests are coalesced: the first request of a batch waits at most `max_wait_ms` for company
-(or until `max_batch` are queued), then ONE recommend_batch() GPU pass runs in a worker thread
-and every caller gets its own slice.  Results are identical to per-request recommend() calls
+requests are coalesced: everything queued while the previous GPU pass was running (plus, when the
+server has seen concurrency, arrivals within `max_wait_ms`, up to `max_batch`) goes into ONE
+recommend_batch() GPU pass in a worker thread and every caller gets its own slice.  Results are identical to per-request recommend() calls
 because packed varlen encoding and per-query top-k are batch-invariant.
 """
 from __future__ import annotations
@@ -76,23 +76,31 @@ class MicroBatcher:
         tm = BatchTimings(len(batch), enc_ms, srch_ms, (time.perf_counter() - t0) * 1000)
         return [r[: p.top_k] for r, p in zip(results, batch)], tm
 
+    def _drain(self, batch: list) -> None:
+        q = self._queue
+        while len(batch) < self.max_batch and not q.empty():
+            batch.append(q.get_nowait())
+
     async def _run(self) -> None:
+        """Continuous batching: while one GPU pass runs in the worker thread, new requests pile up in the
+        queue and the next pass takes all of them at once (no per-request timers).  The `max_wait` window is
+        only opened when the server is idle AND has recently seen concurrency — a lone sequential client is
+        never made to wait for company that is not coming."""
         loop = asyncio.get_running_loop()
+        last_size = 1
         while True:
-            first = await self._queue.get()
-            batch = [first]
-            deadline = loop.time() + self.max_wait
-            while len(batch) < self.max_batch:
-                timeout = deadline - loop.time()
-                if timeout <= 0:
-                    # drain whatever is already queued without waiting
-                    while len(batch) < self.max_batch and not self._queue.empty():
-                        batch.append(self._queue.get_nowait())
-                    break
-                try:
-                    batch.append(await asyncio.wait_for(self._queue.get(), timeout))
-                except asyncio.TimeoutError:
-                    break
+            batch = [await self._queue.get()]
+            await asyncio.sleep(0)  # let every request that is already scheduled enqueue itself
+            self._drain(batch)
+            if len(batch) < self.max_batch and self.max_wait > 0 and (last_size > 1 or len(batch) > 1):
+                deadline = loop.time() + self.max_wait
+                while len(batch) < self.max_batch:
+                    remaining = deadline - loop.time()
+                    if remaining <= 0:
+                        break
+                    await asyncio.sleep(min(remaining, 0.0005))
+                    self._drain(batch)
+            last_size = len(batch)
             try:
                 results, tm = await loop.run_in_executor(self._pool, self._execute, batch)
                 for p, r in zip(batch, results):
