@@ -400,26 +400,38 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
             split8(x, qh[ks], ql[ks]);
         }
     }
-    for (int id = tid; id < nkt * 32 * 8; id += WAVES * 64) {
+    // K/V staging: all of this thread's loads are issued before the first one is consumed (a plain loop
+    // serialises up to four global round trips per workgroup)
+    constexpr int STG = NKT * 32 * 8 / (WAVES * 64);  // = 4 for every bucket
+    f32x4 kreg[STG], vreg[STG];
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+        const int id = tid + it * WAVES * 64;
         const int key = id >> 3, c = id & 7;  // c: 4-dim group
         const int rr = key < L ? key : L - 1;
         const float* src = qkv + (size_t)(t0 + rr) * ld + hd * DH + c * 4;
-        const float4 kv = *reinterpret_cast<const float4*>(src + H);
-        const float4 vv = *reinterpret_cast<const float4*>(src + 2 * H);
-        half4 khi, klo;
-        const float kx[4] = {kv.x, kv.y, kv.z, kv.w}, vx[4] = {vv.x, vv.y, vv.z, vv.w};
+        kreg[it] = *reinterpret_cast<const f32x4*>(src + H);
+        vreg[it] = *reinterpret_cast<const f32x4*>(src + 2 * H);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            _Float16 a, b;
-            split_f16(kx[i], a, b);
-            khi[i] = a; klo[i] = b;
-            split_f16(vx[i], a, b);
-            Vh[(c * 4 + i) * VT + key] = a;
-            Vl[(c * 4 + i) * VT + key] = b;
+    for (int it = 0; it < STG; ++it) {
+        const int id = tid + it * WAVES * 64;
+        if (id < nkt * 32 * 8) {
+            const int key = id >> 3, c = id & 7;
+            half4 khi, klo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 a, b;
+                split_f16(kreg[it][i], a, b);
+                khi[i] = a; klo[i] = b;
+                split_f16(vreg[it][i], a, b);
+                Vh[(c * 4 + i) * VT + key] = a;
+                Vl[(c * 4 + i) * VT + key] = b;
+            }
+            const int off = key * 32 + ((((c >> 1) ^ ((key >> 2) & 3)) << 3) | ((c & 1) << 2));
+            *reinterpret_cast<half4*>(Kh + off) = khi;
+            *reinterpret_cast<half4*>(Kl + off) = klo;
         }
-        const int off = key * 32 + ((((c >> 1) ^ ((key >> 2) & 3)) << 3) | ((c & 1) << 2));
-        *reinterpret_cast<half4*>(Kh + off) = khi;
-        *reinterpret_cast<half4*>(Kl + off) = klo;
     }
     __syncthreads();
     if (qb >= nkt) return;  // idle wave (no barrier below)
