@@ -202,6 +202,32 @@ def main() -> None:
         dt2 = (time.perf_counter() - t2) / 10
         two_stream = {"qps": args.batch / dt2, "ms_per_step": dt2 * 1e3}
 
+    # ---- the same step in the exact-f32 GEMM mode (every linear layer bit-identical to the oracle's fmaf
+    # chains), measured in the same run on the same inputs, plus how far the default mode's embeddings and
+    # top-20 lists are from it: the record carries a plain-fp32 number next to the f16x3 one.
+    f32_leg = None
+    if rank == 0 and world == 1 and not args.no_latency and enc.gemm_mode != "f32":
+        enc32 = DeviceEncoder(weights, shape, dev, gemm_mode="f32")
+        emb32 = torch.empty_like(emb)
+
+        def step32():
+            enc32.encode_packed(ids_d, cu_d, max_len, out=emb32)
+            return search.search(emb32, TOP_K)
+        for _ in range(2):
+            i32, s32 = step32()
+        torch.cuda.synchronize(dev)
+        t32 = time.perf_counter()
+        for _ in range(5):
+            i32, s32 = step32()
+        torch.cuda.synchronize(dev)
+        dt32 = (time.perf_counter() - t32) / 5
+        step()
+        f32_leg = {"qps": args.batch / dt32, "ms_per_step": dt32 * 1e3,
+                   "max_abs_embedding_diff_vs_default_mode": float((emb32 - emb).abs().max().item()),
+                   "top20_lists_identical_to_default_mode": float((i32 == idx).all(dim=1).float().mean().item()),
+                   "note": "gemm_mode=f32: exact-f32 MFMA everywhere (157 TF roof); same inputs, same search"}
+        del enc32, emb32
+
     # ---- single-request latency (Q = 1): what Recommender.recommend() does per request, host-timed
     # from token ids in host memory to k results in host memory.  (a) hipGraph replay (fastpath.py,
     # the product path), (b) the same two library calls launched kernel by kernel.
@@ -324,6 +350,7 @@ def main() -> None:
             "p50_latency_ms_single_request_without_hipgraph": p50_plain_ms,
             "single_request_tokens": int(cu_h[1]),
             "with_two_stream_encode": two_stream,
+            "exact_f32_gemm_mode": f32_leg,
             "from_text_in_host_memory": text_path,
             "catalog_index_build_ms": index_build_ms,
             "catalog_index_build_note": None if index_build_ms is None else
