@@ -139,6 +139,14 @@ ICREC_API int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t 
  * oracle/icrec_oracle.c:icrec_oracle_search_bf16 (same rounded rows, same chain).       */
 #define ICREC_ROWS_F32 0
 #define ICREC_ROWS_BF16 1
+/*   ICREC_ROWS_F32_FILTER  fp32 rows PLUS their f16 hi/lo planes (2x the HBM).  Batches of >= 256 queries
+ *                    are first ranked on the f16 matrix cores (3 MFMAs per product, scores within ~1e-7, 5x
+ *                    the fp32-MFMA rate) keeping k+12 candidates per query; every candidate is then re-scored
+ *                    with the exact fp32 chain and the best k returned.  A query whose (k+12)-th candidate
+ *                    is not provably below its exact k-th score (1e-4 margin) makes the exact search run
+ *                    for the batch instead — results are therefore ALWAYS bit-identical to
+ *                    ICREC_ROWS_F32, only faster for large catalogs x large batches.                    */
+#define ICREC_ROWS_F32_FILTER 2
 ICREC_API int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim,
                           int64_t row_offset, int device, int32_t storage, icrec_index** out);
 ICREC_API int icrec_index_destroy(icrec_index* idx);
@@ -232,7 +240,10 @@ ICREC_API const char* icrec_version(void);
 /* Average duration (ms) of the dominant kernel over the launches recorded
  * since the last reset, measured with hipEvents on the launch stream.
  * which: 0 = search score+select kernel, 1 = encoder FFN-up GEMM,
- *        2 = whole encode() call, 3 = whole search() call.                   */
+ *        2 = whole encode() call, 3 = whole search() call,
+ *        4 = the guarded exact pass behind a filter pass (ICREC_ROWS_F32_FILTER):
+ *            a few microseconds when every query was proven, a full search
+ *            when the fallback ran.                                           */
 ICREC_API int icrec_timing_enable(int on);
 ICREC_API int icrec_timing_reset(void);
 ICREC_API int icrec_timing_query(int which, double* avg_ms, int64_t* n_launches);

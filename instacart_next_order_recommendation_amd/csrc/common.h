@@ -35,7 +35,7 @@ struct TimingSlot {
     double total_ms = 0.0;
     int64_t n = 0;
 };
-enum { T_SEARCH_KERNEL = 0, T_FFN_UP = 1, T_ENCODE = 2, T_SEARCH = 3, T_NSLOTS = 8 };
+enum { T_SEARCH_KERNEL = 0, T_FFN_UP = 1, T_ENCODE = 2, T_SEARCH = 3, T_SEARCH_FALLBACK = 4, T_NSLOTS = 8 };
 bool timing_on();
 // Records [start, stop] around a launch when timing is enabled; resolved lazily at query time.
 struct ScopedTimer {
@@ -71,6 +71,12 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl_xor(lo, m, 64);
     hi = __shfl_xor(hi, m, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src_lane, 64);
+    hi = __shfl(hi, src_lane, 64);
     return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u64 wave_max_u64(u64 v) {

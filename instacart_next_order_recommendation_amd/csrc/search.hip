@@ -7,6 +7,7 @@
 //   the exclusion / top-k Python loop                                    :216-225/:254-262
 // of /root/reference/src/inference/serve_recommendations.py.
 #include "common.h"
+#include "gemm_x3.h"
 
 namespace icrec {
 
@@ -65,11 +66,13 @@ __global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restr
 // candidate queue slots per query between two list merges (more when few queries share the LDS)
 template <class Cfg> struct QCap { static constexpr int V = Cfg::BN <= 32 ? 64 : 16; };
 
-template <class Cfg>
+template <class Cfg, bool X3 = false>
 struct SearchSmem {
+    // operand staging: fp32 tiles (common.h) or the f16 hi/lo planes of the filter pass (gemm_x3.h)
+    static constexpr size_t GEMM = X3 ? (size_t)(2 * Cfg::BM + 2 * Cfg::BN) * HLD * 2 : (size_t)Cfg::LDS_FLOATS * 4;
     // dynamic LDS carve (all offsets multiples of 16 B)
     static __host__ __device__ size_t bytes(int k) {
-        return (size_t)Cfg::LDS_FLOATS * 4 + (size_t)Cfg::BN * (8 /*thr*/ + 4 /*cnt*/) + 16 /*flags*/ +
+        return GEMM + (size_t)Cfg::BN * (8 /*thr*/ + 4 /*cnt*/) + 16 /*flags*/ +
                (size_t)Cfg::BN * k * 8 + (size_t)Cfg::BN * QCap<Cfg>::V * 8;
     }
 };
@@ -113,16 +116,23 @@ __device__ __forceinline__ void merge_queue(u64* list, const u64* queue, int n, 
 // tiles [chunk*tiles_per_chunk, ...) against query tile qtile and keeps, per query, the k best
 // (score, row) seen, then writes them (sorted, as keys) to partial[chunk][query][0..k).
 // EMIT = true additionally stores every score to scores_out[q*N + row] (parity checks only).
-// P16: the catalog rows are stored as bfloat16 (ICREC_ROWS_BF16) and widened on their way into LDS.
-template <class Cfg, bool EMIT, bool P16>
+// PMODE 0: fp32 rows.  1: rows stored as bfloat16 (ICREC_ROWS_BF16), widened on their way into LDS.
+// 2: the FILTER pass of ICREC_ROWS_F32_FILTER — rows and queries as f16 hi/lo planes (P/P2, Qn/Q2), scores from
+//    three f16 MFMAs per product (gemm_x3.h): within ~1e-7 of the exact chain at 5x its MFMA rate, NOT bit-exact;
+//    its lists only nominate candidates for verify_kernel.
+// run_flag != NULL: the whole grid exits unless *run_flag != 0 (the exact pass behind a filter pass).
+template <class Cfg, bool EMIT, int PMODE>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
-    const void* __restrict__ P, int64_t N, int K, const float* __restrict__ Qn, int Qpad, int Q, int k,
-    const int32_t* __restrict__ excl_idx, const int32_t* __restrict__ excl_off, uint32_t row_base,
-    int n_row_tiles, int tiles_per_chunk, int n_qtiles, u64* __restrict__ partial, float* __restrict__ scores_out) {
+    const void* __restrict__ P, const void* __restrict__ P2, int64_t N, int K, const void* __restrict__ Qn,
+    const void* __restrict__ Q2, int Qpad, int Q, int k, const int32_t* __restrict__ excl_idx,
+    const int32_t* __restrict__ excl_off, uint32_t row_base, int n_row_tiles, int tiles_per_chunk, int n_qtiles,
+    u64* __restrict__ partial, float* __restrict__ scores_out, const int* __restrict__ run_flag) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (run_flag != nullptr && *run_flag == 0) return;  // uniform over the grid
+    constexpr bool P16 = PMODE == 1;
     float* As = reinterpret_cast<float*>(smem_raw);
     float* Bs = As + Cfg::BM * LDK;
-    u64* thr = reinterpret_cast<u64*>(Bs + Cfg::BN * LDK);
+    u64* thr = reinterpret_cast<u64*>(smem_raw + SearchSmem<Cfg, PMODE == 2>::GEMM);
     int* cnt = reinterpret_cast<int*>(thr + Cfg::BN);
     int* flags = cnt + Cfg::BN;  // [0],[1]: alternating "some candidate did not fit" flags
     u64* list = reinterpret_cast<u64*>(flags + 4);
@@ -162,7 +172,20 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
 
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int64_t row0 = (int64_t)tile * Cfg::BM;
-        tile_gemm<Cfg, P16>(acc, P, row0, N, Qn, q0, Qpad, K, As, Bs, pre, false);
+        if (PMODE == 2) {
+            f32x16 a0[Cfg::TM][Cfg::TN], a1[Cfg::TM][Cfg::TN];
+            tile_gemm_h<Cfg>(a0, a1, static_cast<const _Float16*>(P), static_cast<const _Float16*>(P2), row0, N,
+                             static_cast<const _Float16*>(Qn), static_cast<const _Float16*>(Q2), q0, Qpad, K,
+                             reinterpret_cast<_Float16*>(smem_raw));
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(a1[i][j][e], LO_UNSCALE, a0[i][j][e]);
+        } else {
+            tile_gemm<Cfg, P16>(acc, P, row0, N, static_cast<const float*>(Qn), q0, Qpad, K, As, Bs, pre, false);
+        }
 
         if (EMIT) {
 #pragma unroll
@@ -467,6 +490,95 @@ __global__ __launch_bounds__(ST_ROWS, 2) void stream_search_kernel(
     for (int i = tid; i < NQ * k; i += ST_ROWS) partial[(size_t)chunk * NQ * k + i] = list[i];
 }
 
+// ---------------------------------------------------------------- filter + verify (ICREC_ROWS_F32_FILTER)
+// fp32 values -> f16 hi/lo planes (queries per call, catalog rows once at create); clears the fallback flag if given.
+__global__ __launch_bounds__(256) void split_queries_kernel(const float* __restrict__ qn, size_t n, _Float16* __restrict__ hi,
+                                                            _Float16* __restrict__ lo, int* __restrict__ flag) {
+    if (flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        _Float16 a, b;
+        split_f16(qn[i], a, b);
+        hi[i] = a;
+        lo[i] = b;
+    }
+}
+
+// Exact re-scoring of the filter pass's candidates.  cand[q][0..kp): the kp best (approximate score, row) keys of
+// query q, sorted; one wavefront per query, two candidates per lane.  Every candidate gets the exact k-ascending
+// fp32 fmaf chain (the oracle's arithmetic) from the fp32 rows, candidates are ranked by (exact score desc, row asc)
+// and the best k written out.  The result is THE exact top-k iff no row outside the list can reach the k-th exact
+// score: outside rows have approx <= the list's last approx score, and |approx - exact| <= eps, so
+//     last_approx + eps < exact_kth    (or the list is not full: it then holds every admissible row)
+// proves it.  Otherwise *flag is set and the exact search that follows (it exits at once when the flag is clear)
+// recomputes the batch.
+__global__ __launch_bounds__(256) void verify_kernel(const float* __restrict__ P, int K, const float* __restrict__ qn,
+                                                     const u64* __restrict__ cand, int Q, int kp, int k, uint32_t row_base,
+                                                     float eps, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                     u64* __restrict__ out_keys, int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float* qv = qn + (size_t)q * K;
+    u64 ek[2];
+    int n_valid = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int c = lane + 64 * s;
+        const u64 ck = c < kp ? cand[(size_t)q * kp + c] : 0ull;
+        ek[s] = 0ull;
+        if (ck != 0ull) {
+            const uint32_t grow = key_row(ck);
+            const float* pr = P + (size_t)(grow - row_base) * K;
+            float acc = 0.0f;
+            for (int j = 0; j < K; j += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(qv + j);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pr + j);
+                acc = fmaf(a[0], b[0], acc);
+                acc = fmaf(a[1], b[1], acc);
+                acc = fmaf(a[2], b[2], acc);
+                acc = fmaf(a[3], b[3], acc);
+            }
+            ek[s] = make_key(acc + 0.0f, grow);
+        }
+        n_valid += __popcll(__ballot(ck != 0ull));
+    }
+    // rank of each exact key among the candidates (keys are unique: the row is part of the key)
+    int rk[2] = {0, 0};
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const u64 o = shfl_u64(ek[s], l);
+            rk[0] += o > ek[0];
+            rk[1] += o > ek[1];
+        }
+    // exact k-th best score (rank k-1), if there are that many candidates
+    float kth = -INFINITY;
+    if (n_valid >= k) {
+        float mine = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (ek[s] != 0ull && rk[s] == k - 1) mine = key_score(ek[s]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mine = fmaxf(mine, __shfl_xor(mine, m, 64));
+        kth = mine;
+    }
+    if (n_valid == kp && lane == 0) {  // full list: rows outside it exist (or may)
+        const float last_approx = key_score(cand[(size_t)q * kp + kp - 1]);
+        if (!(last_approx + eps < kth)) atomicOr(flag, 1);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (ek[s] != 0ull && rk[s] < k) {
+            const size_t o = (size_t)q * k + rk[s];
+            if (out_keys) out_keys[o] = ek[s];
+            if (out_idx) { out_idx[o] = (int64_t)key_row(ek[s]); out_score[o] = key_score(ek[s]); }
+        }
+    for (int e = n_valid + lane; e < k; e += 64) {  // pads when the catalog (minus exclusions) is smaller than k
+        const size_t o = (size_t)q * k + e;
+        if (out_keys) out_keys[o] = 0ull;
+        if (out_idx) { out_idx[o] = -1; out_score[o] = 0.0f; }
+    }
+}
+
 // ---------------------------------------------------------------- k-way merge of sorted lists
 // keys: [n_lists][q_stride][k] sorted descending per (list, query); one wavefront per query
 // runs a tournament: every lane holds the heads of up to MERGE_LPL lists.
@@ -474,10 +586,12 @@ constexpr int MERGE_MAX_LISTS = 1024;
 template <int MERGE_LPL>  // lists per lane: 4 (<= 256 lists) or 16 (<= 1024)
 __global__ __launch_bounds__(256) void merge_kernel(const u64* __restrict__ keys, int n_lists, int q_stride, int Q,
                                                     int k, int64_t* __restrict__ out_idx,
-                                                    float* __restrict__ out_score, u64* __restrict__ out_keys) {
+                                                    float* __restrict__ out_score, u64* __restrict__ out_keys,
+                                                    const int* __restrict__ run_flag = nullptr) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
+    if (run_flag != nullptr && *run_flag == 0) return;
     u64 head[MERGE_LPL];
     int pos[MERGE_LPL];
 #pragma unroll
@@ -514,6 +628,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const u64* __restrict__ keys
 // ---------------------------------------------------------------- host side
 struct Index {
     void* rows = nullptr;  // normalised [n_rows, dim], fp32 or bf16 bits
+    _Float16* plane_hi = nullptr;  // ICREC_ROWS_F32_FILTER: f16 hi/lo planes of `rows` for the filter pass
+    _Float16* plane_lo = nullptr;
     int storage = ICREC_ROWS_F32;
     int64_t n_rows = 0;
     int dim = 0;
@@ -525,6 +641,18 @@ struct Index {
 typedef TileCfg<2, 2, 2, 2> CfgBig;    // 128 rows x 128 queries
 typedef TileCfg<4, 1, 2, 2> CfgMid;    // 256 rows x  64 queries
 typedef TileCfg<4, 1, 2, 1> CfgSmall;  // 256 rows x  32 queries
+typedef TileCfg<2, 2, 2, 1> CfgFilter;  // 128 rows x  64 queries, f16 planes (filter pass)
+
+// Filter + verify (ICREC_ROWS_F32_FILTER): batches of at least FILTER_MIN_Q queries are ranked by the f16x3 filter
+// pass with FILTER_SLACK extra list entries, then verified exactly.  FILTER_EPS bounds |filter score - exact score|
+// for unit vectors: the f16 split drops <= 3 * 2^-22 per product (Cauchy-Schwarz: <= 7.2e-7 per score) and either
+// fp32 accumulation is off by at most 384 * 2^-24 = 2.3e-5 from the real dot product; 1e-4 covers the sum twice.
+// Below 256 queries the pass's fixed costs (three more launches, longer lists) eat its advantage: measured at
+// 49,688 rows Q=64 0.26 ms vs 0.15 ms exact, Q=256 equal, Q=1024 0.61 vs 0.82 ms; at 2M rows Q=256 2.5 vs 4.2 ms,
+// Q=1024 7.5 vs 14.5 ms.
+constexpr int FILTER_MIN_Q = 256, FILTER_SLACK = 12;
+constexpr float FILTER_EPS = 1.0e-4f;
+static inline int filter_list_len(int k) { int kp = k + FILTER_SLACK; kp = (kp + 7) & ~7; return kp; }
 
 struct Plan {
     int variant;  // 0 big, 1 mid, 2 small
@@ -599,8 +727,9 @@ static int launch_stream(const Index* ix, const Plan& p, const float* qn, int Q,
 
 template <class Cfg, bool EMIT, bool P16>
 static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q, int k, const int32_t* ei,
-                         const int32_t* eo, u64* partial, float* scores_out, hipStream_t st) {
-    auto kern = search_kernel<Cfg, EMIT, P16>;
+                         const int32_t* eo, u64* partial, float* scores_out, hipStream_t st,
+                         const int* run_flag = nullptr) {
+    auto kern = search_kernel<Cfg, EMIT, P16 ? 1 : 0>;
     static bool attr_set = false;
     if (!attr_set) {
         ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -609,11 +738,99 @@ static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q,
     }
     const int grid = p.n_chunks * p.n_qtiles;
     {
-        ScopedTimer tm(T_SEARCH_KERNEL, st);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), p.smem, st, (const void*)ix->rows, ix->n_rows, ix->dim, qn, p.Qpad,
-                           Q, k, ei, eo, (uint32_t)ix->row_offset, p.n_row_tiles, p.tiles_per_chunk, p.n_qtiles,
-                           partial, scores_out);
+        ScopedTimer tm(run_flag == nullptr ? T_SEARCH_KERNEL : T_SEARCH_FALLBACK, st);  // the guarded pass has its own slot
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), p.smem, st, (const void*)ix->rows, (const void*)nullptr,
+                           ix->n_rows, ix->dim, (const void*)qn, (const void*)nullptr, p.Qpad, Q, k, ei, eo,
+                           (uint32_t)ix->row_offset, p.n_row_tiles, p.tiles_per_chunk, p.n_qtiles, partial, scores_out,
+                           run_flag);
     }
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
+}
+
+// Workspace of the filter + verify path: [qn fp32 | q hi | q lo | flag | candidate keys | partial lists (filter pass,
+// then reused by the guarded exact pass)].
+struct FilterPlan {
+    bool use;
+    int kp, Qpad, n_qtiles, n_row_tiles, tiles_per_chunk, n_chunks;
+    size_t smem, off_qh, off_ql, off_flag, off_cand, off_partial, ws_total;
+};
+
+static FilterPlan make_filter_plan(const Index* ix, int Q, int k, const Plan& exact) {
+    FilterPlan f;
+    f.kp = filter_list_len(k);
+    f.use = ix->plane_hi != nullptr && Q >= FILTER_MIN_Q && f.kp <= ICREC_MAX_K;
+    if (!f.use) { f.ws_total = 0; return f; }
+    f.n_qtiles = (Q + CfgFilter::BN - 1) / CfgFilter::BN;
+    f.Qpad = f.n_qtiles * CfgFilter::BN;
+    f.n_row_tiles = (int)((ix->n_rows + CfgFilter::BM - 1) / CfgFilter::BM);
+    int want_chunks = (2 * ix->n_cu) / f.n_qtiles;
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > 256) want_chunks = 256;
+    if (want_chunks > f.n_row_tiles) want_chunks = f.n_row_tiles;
+    f.tiles_per_chunk = (f.n_row_tiles + want_chunks - 1) / want_chunks;
+    f.n_chunks = (f.n_row_tiles + f.tiles_per_chunk - 1) / f.tiles_per_chunk;
+    f.smem = SearchSmem<CfgFilter, true>::bytes(f.kp);
+    const int qpad_max = f.Qpad > exact.Qpad ? f.Qpad : exact.Qpad;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    f.off_qh = up((size_t)qpad_max * ix->dim * 4);
+    f.off_ql = f.off_qh + up((size_t)f.Qpad * ix->dim * 2);
+    f.off_flag = f.off_ql + up((size_t)f.Qpad * ix->dim * 2);
+    f.off_cand = f.off_flag + 256;
+    f.off_partial = f.off_cand + up((size_t)Q * f.kp * 8);
+    const size_t part_filter = (size_t)f.n_chunks * f.Qpad * f.kp * 8;
+    f.ws_total = f.off_partial + up(part_filter > exact.ws_partial ? part_filter : exact.ws_partial);
+    return f;
+}
+
+static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei, const int32_t* eo, int64_t* out_idx,
+                      float* out_score, u64* out_keys, float* scores_out, void* ws, size_t ws_bytes, hipStream_t st);
+
+// Filter (f16x3 MFMA, approximate) -> merge -> verify (exact chains on the candidates) -> exact search that runs
+// only if some query could not be proven.  Same outputs, bit for bit, as the exact search.
+static int run_search_filtered(Index* ix, const FilterPlan& f, const Plan& ex, const float* q, int Q, int k,
+                               const int32_t* ei, const int32_t* eo, int64_t* out_idx, float* out_score, u64* out_keys,
+                               void* ws, hipStream_t st) {
+    char* base = reinterpret_cast<char*>(ws);
+    float* qn = reinterpret_cast<float*>(base);
+    _Float16* qh = reinterpret_cast<_Float16*>(base + f.off_qh);
+    _Float16* ql = reinterpret_cast<_Float16*>(base + f.off_ql);
+    int* flag = reinterpret_cast<int*>(base + f.off_flag);
+    u64* cand = reinterpret_cast<u64*>(base + f.off_cand);
+    u64* partial = reinterpret_cast<u64*>(base + f.off_partial);
+    const int qpad_max = f.Qpad > ex.Qpad ? f.Qpad : ex.Qpad;
+    hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((qpad_max + 3) / 4), dim3(256), 0, st, q, (void*)qn, (int64_t)Q,
+                       (int64_t)qpad_max, ix->dim, 1e-12f, 0);
+    const size_t nq = (size_t)f.Qpad * ix->dim;
+    hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)((nq + 255) / 256 < 1024 ? (nq + 255) / 256 : 1024)), dim3(256), 0,
+                       st, qn, nq, qh, ql, flag);
+    {
+        auto kern = search_kernel<CfgFilter, false, 2>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 * 1024));
+            attr_set = true;
+        }
+        ScopedTimer tm(T_SEARCH_KERNEL, st);
+        hipLaunchKernelGGL(kern, dim3(f.n_chunks * f.n_qtiles), dim3(CfgFilter::THREADS), f.smem, st,
+                           (const void*)ix->plane_hi, (const void*)ix->plane_lo, ix->n_rows, ix->dim, (const void*)qh,
+                           (const void*)ql, f.Qpad, Q, f.kp, ei, eo, (uint32_t)ix->row_offset, f.n_row_tiles,
+                           f.tiles_per_chunk, f.n_qtiles, partial, (float*)nullptr, (const int*)nullptr);
+    }
+    ICREC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(merge_kernel<4>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, f.n_chunks, f.Qpad, Q, f.kp,
+                       (int64_t*)nullptr, (float*)nullptr, cand, (const int*)nullptr);
+    hipLaunchKernelGGL(verify_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, static_cast<const float*>(ix->rows), ix->dim, qn,
+                       cand, Q, f.kp, k, (uint32_t)ix->row_offset, FILTER_EPS, out_idx, out_score, out_keys, flag);
+    ICREC_HIP(hipGetLastError());
+    // exact pass: every workgroup returns at once unless verify raised the flag
+    int rc = ex.variant == 0   ? launch_search<CfgBig, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
+             : ex.variant == 1 ? launch_search<CfgMid, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
+                               : launch_search<CfgSmall, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag);
+    if (rc != ICREC_OK) return rc;
+    hipLaunchKernelGGL(merge_kernel<4>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, ex.n_chunks, ex.Qpad, Q, k, out_idx,
+                       out_score, out_keys, (const int*)flag);
     ICREC_HIP(hipGetLastError());
     return ICREC_OK;
 }
@@ -624,6 +841,19 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     ICREC_REQUIRE(Q >= 1, "icrec_search: n_queries must be >= 1 (got %d)", Q);
     ICREC_REQUIRE(k >= 1 && k <= ICREC_MAX_K, "icrec_search: k must be in [1, %d] (got %d)", ICREC_MAX_K, k);
     ICREC_REQUIRE((ei == nullptr) == (eo == nullptr), "icrec_search: excl_idx and excl_off must both be set or both NULL");
+    if (scores_out == nullptr && ix->plane_hi != nullptr) {
+        const Plan ex = make_plan(ix, Q, k, false);
+        const FilterPlan f = make_filter_plan(ix, Q, k, ex);
+        if (f.use) {
+            if (ws_bytes < f.ws_total || ws == nullptr) {
+                set_error("icrec_search: workspace too small (%zu < %zu)", ws_bytes, f.ws_total);
+                return ICREC_ENOMEM;
+            }
+            ICREC_HIP(hipSetDevice(ix->device));
+            ScopedTimer whole(T_SEARCH, st);
+            return run_search_filtered(ix, f, ex, q, Q, k, ei, eo, out_idx, out_score, out_keys, ws, st);
+        }
+    }
     const Plan p = make_plan(ix, Q, k, scores_out == nullptr);
     if (ws_bytes < p.ws_total || ws == nullptr) {
         set_error("icrec_search: workspace too small (%zu < %zu)", ws_bytes, p.ws_total);
@@ -675,8 +905,10 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     ICREC_REQUIRE(n_rows >= 1, "icrec_index_create: n_rows must be >= 1");
     ICREC_REQUIRE(dim >= BK && dim % BK == 0 && dim <= 4096, "icrec_index_create: dim must be a multiple of %d (got %d)", BK, dim);
     ICREC_REQUIRE(row_offset >= 0 && row_offset + n_rows < 0xFFFFFFFFll, "icrec_index_create: row_offset + n_rows must be < 2^32-1");
-    ICREC_REQUIRE(storage == ICREC_ROWS_F32 || storage == ICREC_ROWS_BF16,
-                  "icrec_index_create: storage must be ICREC_ROWS_F32 (0) or ICREC_ROWS_BF16 (1), got %d", storage);
+    ICREC_REQUIRE(storage == ICREC_ROWS_F32 || storage == ICREC_ROWS_BF16 || storage == ICREC_ROWS_F32_FILTER,
+                  "icrec_index_create: storage must be ICREC_ROWS_F32 (0), ICREC_ROWS_BF16 (1) or ICREC_ROWS_F32_FILTER (2), got %d", storage);
+    ICREC_REQUIRE(storage != ICREC_ROWS_F32_FILTER || dim % HBK == 0,
+                  "icrec_index_create: ICREC_ROWS_F32_FILTER needs dim %% %d == 0 (got %d)", HBK, dim);
     ICREC_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     ICREC_HIP(hipGetDeviceProperties(&prop, device));
@@ -700,6 +932,19 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     else
         hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
     ICREC_HIP(hipGetLastError());
+    if (storage == ICREC_ROWS_F32_FILTER) {
+        const size_t n = (size_t)n_rows * dim;
+        hipError_t e1 = hipMalloc(&ix->plane_hi, n * 2), e2 = hipMalloc(&ix->plane_lo, n * 2);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            hipFree(ix->plane_hi); hipFree(ix->plane_lo); hipFree(ix->rows);
+            delete ix;
+            set_error("icrec_index_create: hipMalloc of the filter planes (2 x %zu bytes) failed", n * 2);
+            return ICREC_ENOMEM;
+        }
+        hipLaunchKernelGGL(split_queries_kernel, dim3(4096), dim3(256), 0, 0, static_cast<const float*>(ix->rows), n,
+                           ix->plane_hi, ix->plane_lo, (int*)nullptr);
+        ICREC_HIP(hipGetLastError());
+    }
     ICREC_HIP(hipStreamSynchronize(0));
     *out = reinterpret_cast<icrec_index*>(ix);
     return ICREC_OK;
@@ -717,6 +962,8 @@ int icrec_index_destroy(icrec_index* h) {
     if (!ix) return ICREC_OK;
     hipSetDevice(ix->device);
     hipFree(ix->rows);
+    hipFree(ix->plane_hi);
+    hipFree(ix->plane_lo);
     delete ix;
     return ICREC_OK;
 }
@@ -741,8 +988,10 @@ int icrec_index_export(const icrec_index* h, float* rows_dev, void* stream) {
 size_t icrec_search_workspace_bytes(const icrec_index* h, int32_t n_queries, int32_t k) {
     const Index* ix = reinterpret_cast<const Index*>(h);
     if (!ix || n_queries < 1 || k < 1 || k > ICREC_MAX_K) return 0;
-    const size_t a = make_plan(ix, n_queries, k, false).ws_total, b = make_plan(ix, n_queries, k, true).ws_total;
-    return a > b ? a : b;
+    const Plan ex = make_plan(ix, n_queries, k, false);
+    const size_t a = ex.ws_total, b = make_plan(ix, n_queries, k, true).ws_total;
+    const size_t c = make_filter_plan(ix, n_queries, k, ex).ws_total;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 int icrec_search(icrec_index* h, const float* q_dev, int32_t n_queries, int32_t k, const int32_t* excl_idx_dev,

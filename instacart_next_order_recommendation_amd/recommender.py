@@ -149,7 +149,10 @@ class Recommender:
         self.device = self._inference_device()
         self.model = self._load_model()
         self.product_embeddings = self._load_or_build_embeddings(batch_size, use_index)
-        self._index = DeviceIndex(self.product_embeddings, self.device)
+        # fp32 rows + f16 filter planes: large batches (>= 256 queries) rank on the f16 matrix cores and are verified
+        # exactly — same bits out as plain "f32" (ICREC_INDEX_STORAGE=f32 turns the planes off, =bf16 halves the rows)
+        self._index = DeviceIndex(self.product_embeddings, self.device,
+                                  storage=os.getenv("ICREC_INDEX_STORAGE", "f32+filter"))
         self._fast = None
         if os.getenv("ICREC_USE_GRAPH", "1") != "0":
             from .fastpath import SingleRequestPath

@@ -45,14 +45,17 @@ def exclusion_csr(exclude: Optional[Sequence[Iterable[int]]], n_queries: int, de
     return idx, torch.from_numpy(off).to(device)
 
 
-ROW_STORAGE = {"f32": 0, "bf16": 1}  # ICREC_ROWS_* in include/icrec.h
+ROW_STORAGE = {"f32": 0, "bf16": 1, "f32+filter": 2}  # ICREC_ROWS_* in include/icrec.h
 
 
 class DeviceIndex:
     """A row shard of the product-embedding matrix, normalised and resident on one GPU.
 
     storage="bf16" keeps the normalised rows as bfloat16 (half the HBM; BASELINE config 5's 10M-row
-    catalog); the arithmetic stays the exact fp32 fmaf chain over the widened values."""
+    catalog); the arithmetic stays the exact fp32 fmaf chain over the widened values.
+    storage="f32+filter" keeps fp32 rows plus their f16 hi/lo planes (2x the HBM): batches of >= 256 queries are
+    ranked on the f16 matrix cores first and the candidates re-scored exactly — same bits out, several times
+    faster on large catalogs (see ICREC_ROWS_F32_FILTER in include/icrec.h)."""
 
     def __init__(self, embeddings, device: str | torch.device = "cuda:0", row_offset: int = 0,
                  storage: str = "f32"):

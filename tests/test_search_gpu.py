@@ -290,3 +290,92 @@ def test_merge_many_lists(torch_cuda):
     want_i, want_s = _oracle().merge(idx, sc)
     np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
     np.testing.assert_array_equal(got_s.cpu().numpy(), want_s)
+
+
+# ---------------------------------------------------------------- filter + verify (ICREC_ROWS_F32_FILTER)
+@pytest.mark.parametrize("nq,k,n", [(256, 20, 1000), (300, 50, 3000), (513, 20, 5000), (384, 100, 2049), (257, 1, 777),
+                                      (260, 116, 4000), (256, 120, 3000), (70, 20, 3000)])
+def test_filter_index_is_bit_identical_to_exact(torch_cuda, nq, k, n):
+    """f16x3 filter pass + exact verification returns the exact search's bits (indices, scores), with
+    exclusions; k + slack > 128 and batches under 256 queries (last two cases) silently take the exact path."""
+    rng = np.random.default_rng(nq * 31 + k)
+    P = rng.standard_normal((n, 384)).astype(np.float32)
+    q = rng.standard_normal((nq, 384)).astype(np.float32)
+    excl = [rng.choice(n, size=rng.integers(0, min(n, 40)), replace=False).tolist() for _ in range(nq)]
+    want_i, want_s = _oracle().search(q, P, k, excl)
+    ix = _search_mod().DeviceIndex(P, storage="f32+filter")
+    idx, sc = ix.search(q, k, excl)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want_s)
+    keys = ix.search_partial(q, k, excl)
+    idx2, sc2 = _search_mod().merge_topk(keys.unsqueeze(0), k)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(sc2.cpu().numpy(), want_s)
+
+
+def test_filter_falls_back_when_it_cannot_prove_the_result(torch_cuda):
+    """Adversarial ties: 300 identical rows (more than any candidate list holds) are every query's best match,
+    plus blocks of near-ties 1e-6 apart.  The verify pass cannot prove these, raises its flag, and the exact
+    pass must deliver the oracle's answer (lower row first among equals)."""
+    rng = np.random.default_rng(9)
+    n, nq, k = 6000, 288, 20
+    P = rng.standard_normal((n, 384)).astype(np.float32)
+    base = rng.standard_normal(384).astype(np.float32)
+    dup = rng.choice(n, 300, replace=False)
+    P[dup] = base
+    near = rng.choice(np.setdiff1d(np.arange(n), dup), 200, replace=False)
+    P[near] = base + 1e-6 * rng.standard_normal((200, 384)).astype(np.float32)
+    q = base[None, :] + 0.05 * rng.standard_normal((nq, 384)).astype(np.float32)
+    want_i, want_s = _oracle().search(q, P, k)
+    ix = _search_mod().DeviceIndex(P, storage="f32+filter")
+    idx, sc = ix.search(q, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want_s)
+    # a small catalog where k exceeds the admissible rows (lists not full -> proven complete, pads)
+    Ps = P[:30]
+    excl = [list(range(0, 30, 2))] * 288
+    wi, ws = _oracle().search(q, Ps, 20, excl)
+    i2, s2 = _search_mod().DeviceIndex(Ps, storage="f32+filter").search(q, 20, excl)
+    np.testing.assert_array_equal(i2.cpu().numpy(), wi)
+    np.testing.assert_array_equal(s2.cpu().numpy(), ws)
+
+
+def test_filter_full_catalog_batch(torch_cuda):
+    """BASELINE configs[2] size through the filter path: 1,024 x 49,688, all lists equal to the exact index's —
+    and proven by the verify pass alone: the guarded exact pass (timer slot 4) exits at once, whereas the
+    adversarial catalog of the previous test makes it run."""
+    torch = torch_cuda
+    from instacart_next_order_recommendation_amd import _native
+
+    syn = _syn()
+    P = syn.synthetic_embeddings(49688, 384, seed=1)
+    q = syn.synthetic_embeddings(1024, 384, seed=3)
+    S = _search_mod()
+    exact = S.DeviceIndex(P)
+    ie, se = exact.search(q, 20)
+    fx = S.DeviceIndex(P, storage="f32+filter")
+    fx.search(q, 20)
+    torch.cuda.synchronize()
+    _native.timing_reset(); _native.timing_enable(True)
+    fi, fs = fx.search(q, 20)
+    exact.search(q, 20)
+    torch.cuda.synchronize()
+    _native.timing_enable(False)
+    assert torch.equal(ie, fi) and torch.equal(se, fs)
+    fallback_ms, n_fb = _native.timing_query(4)
+    exact_ms, _ = _native.timing_query(0)
+    assert n_fb == 1 and fallback_ms < 0.1 * exact_ms, (fallback_ms, exact_ms)  # exited at once: nothing was flagged
+    # the adversarial case: the fallback really runs
+    rng = np.random.default_rng(9)
+    Pd = rng.standard_normal((6000, 384)).astype(np.float32)
+    Pd[rng.choice(6000, 300, replace=False)] = Pd[0]
+    qd = Pd[0][None, :] + 0.05 * rng.standard_normal((288, 384)).astype(np.float32)
+    fd = S.DeviceIndex(Pd, storage="f32+filter")
+    fd.search(qd, 20)
+    torch.cuda.synchronize()
+    _native.timing_reset(); _native.timing_enable(True)
+    fd.search(qd, 20)
+    torch.cuda.synchronize()
+    _native.timing_enable(False)
+    fb2, _ = _native.timing_query(4)
+    assert fb2 > 3 * fallback_ms, (fb2, fallback_ms)
