@@ -66,7 +66,16 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
     t1 = time.perf_counter()
     oracle.search(emb, catalog, TOP_K, None)
     t2 = time.perf_counter()
+    # one request at a time, as the reference serves them (its README: 119.9 ms per request on its CPU): encode
+    # ONE context, normalise the catalog + cos_sim + full argsort + top-20; p50 of 5
+    one = []
+    for r in range(5):
+        a = time.perf_counter()
+        e1 = oracle.encode(weights, cfg, ids[cu[r]:cu[r + 1]], np.array([0, cu[r + 1] - cu[r]], np.int32))
+        oracle.search(e1, catalog, TOP_K, None)
+        one.append((time.perf_counter() - a) * 1e3)
     return {"value": n_sample / (t2 - t0), "unit": "queries/s", "cores": oracle.threads(), "kind": "port",
+            "single_request_p50_ms": float(np.median(one)),
             "sample": f"{n_sample} of the step's contexts ({int(cu_s[-1])} tokens): oracle encode {t1 - t0:.2f}s + "
                       f"cos_sim/argsort/top-{TOP_K} over {catalog.shape[0]} rows {t2 - t1:.2f}s (OpenMP C port, "
                       f"batched; the reference serves one request at a time)"}
