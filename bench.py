@@ -41,9 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="user contexts per GPU per step")
     ap.add_argument("--workload", default="49k7", choices=["49k7", "10m"])
-    ap.add_argument("--catalog-rows", default=None, choices=["f32", "bf16", "f32+filter"],
+    ap.add_argument("--catalog-rows", default=None, choices=["f32", "bf16", "f32+filter", "bf16+filter"],
                     help="how the index keeps its rows in HBM (default: f32+filter for 49k7 — what Recommender uses: fp32 rows "
-                         "plus f16 filter planes, results bit-identical to f32; bf16 for 10m as BASELINE configs[4] says)")
+                         "plus f16 filter planes, results bit-identical to f32; bf16+filter for 10m: bf16 rows as BASELINE configs[4] says, plus filter planes)")
     ap.add_argument("--gemm-mode", default=None, choices=["f32", "f16x3"],
                     help="encoder GEMM arithmetic (default: the package default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,7 +151,7 @@ def main() -> None:
             m = min(1 << 18, hi - lo - s)
             cid = torch.randint(0, 200, (m,), device=dev, generator=g)
             shard[s:s + m] = centres[cid] + 0.35 * torch.randn(m, shape.hidden, device=dev, generator=g)
-    row_storage = args.catalog_rows or ("f32+filter" if args.workload == "49k7" else "bf16")
+    row_storage = args.catalog_rows or ("f32+filter" if args.workload == "49k7" else "bf16+filter")
     backend = HipShardBackend(shard, lo, dev, storage=row_storage)
     del shard
     search = ShardedSearch(backend, lo, hi)

@@ -147,6 +147,10 @@ ICREC_API int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t 
  *                    for the batch instead — results are therefore ALWAYS bit-identical to
  *                    ICREC_ROWS_F32, only faster for large catalogs x large batches.                    */
 #define ICREC_ROWS_F32_FILTER 2
+/*   ICREC_ROWS_BF16_FILTER  the same two-pass search over ICREC_ROWS_BF16 rows: bf16 rows (the exact pass and the
+ *                    verification read these) plus f16 hi/lo planes of the rounded rows (3x the bf16 bytes
+ *                    in total); bit-identical to ICREC_ROWS_BF16.                                        */
+#define ICREC_ROWS_BF16_FILTER 3
 ICREC_API int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim,
                           int64_t row_offset, int device, int32_t storage, icrec_index** out);
 ICREC_API int icrec_index_destroy(icrec_index* idx);

@@ -492,12 +492,15 @@ __global__ __launch_bounds__(ST_ROWS, 2) void stream_search_kernel(
 
 // ---------------------------------------------------------------- filter + verify (ICREC_ROWS_F32_FILTER)
 // fp32 values -> f16 hi/lo planes (queries per call, catalog rows once at create); clears the fallback flag if given.
-__global__ __launch_bounds__(256) void split_queries_kernel(const float* __restrict__ qn, size_t n, _Float16* __restrict__ hi,
+template <bool SRC16>  // SRC16: the source is bfloat16 bits (ICREC_ROWS_BF16_FILTER rows), widened exactly first
+__global__ __launch_bounds__(256) void split_queries_kernel(const void* __restrict__ src, size_t n, _Float16* __restrict__ hi,
                                                             _Float16* __restrict__ lo, int* __restrict__ flag) {
     if (flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = SRC16 ? __uint_as_float((unsigned)static_cast<const uint16_t*>(src)[i] << 16)
+                              : static_cast<const float*>(src)[i];
         _Float16 a, b;
-        split_f16(qn[i], a, b);
+        split_f16(v, a, b);
         hi[i] = a;
         lo[i] = b;
     }
@@ -511,7 +514,8 @@ __global__ __launch_bounds__(256) void split_queries_kernel(const float* __restr
 //     last_approx + eps < exact_kth    (or the list is not full: it then holds every admissible row)
 // proves it.  Otherwise *flag is set and the exact search that follows (it exits at once when the flag is clear)
 // recomputes the batch.
-__global__ __launch_bounds__(256) void verify_kernel(const float* __restrict__ P, int K, const float* __restrict__ qn,
+template <bool P16>  // P16: rows are bfloat16 bits, widened exactly (the arithmetic of the bf16 exact search)
+__global__ __launch_bounds__(256) void verify_kernel(const void* __restrict__ Pv, int K, const float* __restrict__ qn,
                                                      const u64* __restrict__ cand, int Q, int kp, int k, uint32_t row_base,
                                                      float eps, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                      u64* __restrict__ out_keys, int* __restrict__ flag) {
@@ -528,15 +532,27 @@ __global__ __launch_bounds__(256) void verify_kernel(const float* __restrict__ P
         ek[s] = 0ull;
         if (ck != 0ull) {
             const uint32_t grow = key_row(ck);
-            const float* pr = P + (size_t)(grow - row_base) * K;
             float acc = 0.0f;
-            for (int j = 0; j < K; j += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(qv + j);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(pr + j);
-                acc = fmaf(a[0], b[0], acc);
-                acc = fmaf(a[1], b[1], acc);
-                acc = fmaf(a[2], b[2], acc);
-                acc = fmaf(a[3], b[3], acc);
+            if (P16) {
+                const uint16_t* pr = static_cast<const uint16_t*>(Pv) + (size_t)(grow - row_base) * K;
+                for (int j = 0; j < K; j += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(qv + j);
+                    const uint2 w = *reinterpret_cast<const uint2*>(pr + j);
+                    acc = fmaf(a[0], __uint_as_float(w.x << 16), acc);
+                    acc = fmaf(a[1], __uint_as_float(w.x & 0xFFFF0000u), acc);
+                    acc = fmaf(a[2], __uint_as_float(w.y << 16), acc);
+                    acc = fmaf(a[3], __uint_as_float(w.y & 0xFFFF0000u), acc);
+                }
+            } else {
+                const float* pr = static_cast<const float*>(Pv) + (size_t)(grow - row_base) * K;
+                for (int j = 0; j < K; j += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(qv + j);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(pr + j);
+                    acc = fmaf(a[0], b[0], acc);
+                    acc = fmaf(a[1], b[1], acc);
+                    acc = fmaf(a[2], b[2], acc);
+                    acc = fmaf(a[3], b[3], acc);
+                }
             }
             ek[s] = make_key(acc + 0.0f, grow);
         }
@@ -637,6 +653,8 @@ struct Index {
     int device = 0;
     int n_cu = 256;
 };
+
+static inline bool rows_are_bf16(const Index* ix) { return ix->storage == ICREC_ROWS_BF16 || ix->storage == ICREC_ROWS_BF16_FILTER; }
 
 typedef TileCfg<2, 2, 2, 2> CfgBig;    // 128 rows x 128 queries
 typedef TileCfg<4, 1, 2, 2> CfgMid;    // 256 rows x  64 queries
@@ -802,8 +820,8 @@ static int run_search_filtered(Index* ix, const FilterPlan& f, const Plan& ex, c
     hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((qpad_max + 3) / 4), dim3(256), 0, st, q, (void*)qn, (int64_t)Q,
                        (int64_t)qpad_max, ix->dim, 1e-12f, 0);
     const size_t nq = (size_t)f.Qpad * ix->dim;
-    hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)((nq + 255) / 256 < 1024 ? (nq + 255) / 256 : 1024)), dim3(256), 0,
-                       st, qn, nq, qh, ql, flag);
+    hipLaunchKernelGGL(split_queries_kernel<false>, dim3((unsigned)((nq + 255) / 256 < 1024 ? (nq + 255) / 256 : 1024)),
+                       dim3(256), 0, st, (const void*)qn, nq, qh, ql, flag);
     {
         auto kern = search_kernel<CfgFilter, false, 2>;
         static bool attr_set = false;
@@ -821,11 +839,22 @@ static int run_search_filtered(Index* ix, const FilterPlan& f, const Plan& ex, c
     ICREC_HIP(hipGetLastError());
     hipLaunchKernelGGL(merge_kernel<4>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, f.n_chunks, f.Qpad, Q, f.kp,
                        (int64_t*)nullptr, (float*)nullptr, cand, (const int*)nullptr);
-    hipLaunchKernelGGL(verify_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, static_cast<const float*>(ix->rows), ix->dim, qn,
-                       cand, Q, f.kp, k, (uint32_t)ix->row_offset, FILTER_EPS, out_idx, out_score, out_keys, flag);
+    const bool h = rows_are_bf16(ix);
+    if (h)
+        hipLaunchKernelGGL(verify_kernel<true>, dim3((Q + 3) / 4), dim3(256), 0, st, (const void*)ix->rows, ix->dim, qn, cand, Q,
+                           f.kp, k, (uint32_t)ix->row_offset, FILTER_EPS, out_idx, out_score, out_keys, flag);
+    else
+        hipLaunchKernelGGL(verify_kernel<false>, dim3((Q + 3) / 4), dim3(256), 0, st, (const void*)ix->rows, ix->dim, qn, cand, Q,
+                           f.kp, k, (uint32_t)ix->row_offset, FILTER_EPS, out_idx, out_score, out_keys, flag);
     ICREC_HIP(hipGetLastError());
     // exact pass: every workgroup returns at once unless verify raised the flag
-    int rc = ex.variant == 0   ? launch_search<CfgBig, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
+    int rc;
+    if (h)
+        rc = ex.variant == 0   ? launch_search<CfgBig, false, true>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
+             : ex.variant == 1 ? launch_search<CfgMid, false, true>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
+                               : launch_search<CfgSmall, false, true>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag);
+    else
+        rc = ex.variant == 0   ? launch_search<CfgBig, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
              : ex.variant == 1 ? launch_search<CfgMid, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag)
                                : launch_search<CfgSmall, false, false>(ix, ex, qn, Q, k, ei, eo, partial, nullptr, st, flag);
     if (rc != ICREC_OK) return rc;
@@ -871,13 +900,13 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
      : p.variant == 1 ? launch_search<CfgMid, EMIT, P16>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)          \
                       : launch_search<CfgSmall, EMIT, P16>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st))
     if (p.variant == 3) {
-        const bool h = ix->storage == ICREC_ROWS_BF16;
+        const bool h = rows_are_bf16(ix);
 #define ICREC_STREAM_DISPATCH(NQ) \
     (h ? launch_stream<NQ, true>(ix, p, qn, Q, k, ei, eo, partial, st) : launch_stream<NQ, false>(ix, p, qn, Q, k, ei, eo, partial, st))
         rc = p.BN == 1 ? ICREC_STREAM_DISPATCH(1) : p.BN == 2 ? ICREC_STREAM_DISPATCH(2) : p.BN == 4 ? ICREC_STREAM_DISPATCH(4)
                                                                                                    : ICREC_STREAM_DISPATCH(8);
 #undef ICREC_STREAM_DISPATCH
-    } else if (ix->storage == ICREC_ROWS_BF16) rc = scores_out ? ICREC_SEARCH_DISPATCH(true, true) : ICREC_SEARCH_DISPATCH(false, true);
+    } else if (rows_are_bf16(ix)) rc = scores_out ? ICREC_SEARCH_DISPATCH(true, true) : ICREC_SEARCH_DISPATCH(false, true);
     else rc = scores_out ? ICREC_SEARCH_DISPATCH(true, false) : ICREC_SEARCH_DISPATCH(false, false);
 #undef ICREC_SEARCH_DISPATCH
     if (rc != ICREC_OK) return rc;
@@ -905,10 +934,11 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     ICREC_REQUIRE(n_rows >= 1, "icrec_index_create: n_rows must be >= 1");
     ICREC_REQUIRE(dim >= BK && dim % BK == 0 && dim <= 4096, "icrec_index_create: dim must be a multiple of %d (got %d)", BK, dim);
     ICREC_REQUIRE(row_offset >= 0 && row_offset + n_rows < 0xFFFFFFFFll, "icrec_index_create: row_offset + n_rows must be < 2^32-1");
-    ICREC_REQUIRE(storage == ICREC_ROWS_F32 || storage == ICREC_ROWS_BF16 || storage == ICREC_ROWS_F32_FILTER,
-                  "icrec_index_create: storage must be ICREC_ROWS_F32 (0), ICREC_ROWS_BF16 (1) or ICREC_ROWS_F32_FILTER (2), got %d", storage);
-    ICREC_REQUIRE(storage != ICREC_ROWS_F32_FILTER || dim % HBK == 0,
-                  "icrec_index_create: ICREC_ROWS_F32_FILTER needs dim %% %d == 0 (got %d)", HBK, dim);
+    ICREC_REQUIRE(storage >= ICREC_ROWS_F32 && storage <= ICREC_ROWS_BF16_FILTER,
+                  "icrec_index_create: storage must be one of ICREC_ROWS_F32 (0), _BF16 (1), _F32_FILTER (2), _BF16_FILTER (3), got %d", storage);
+    const bool with_planes = storage == ICREC_ROWS_F32_FILTER || storage == ICREC_ROWS_BF16_FILTER;
+    const bool rows16 = storage == ICREC_ROWS_BF16 || storage == ICREC_ROWS_BF16_FILTER;
+    ICREC_REQUIRE(!with_planes || dim % HBK == 0, "icrec_index_create: the filter planes need dim %% %d == 0 (got %d)", HBK, dim);
     ICREC_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     ICREC_HIP(hipGetDeviceProperties(&prop, device));
@@ -919,7 +949,7 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     Index* ix = new Index();
     ix->n_rows = n_rows; ix->dim = dim; ix->row_offset = row_offset; ix->device = device; ix->storage = storage;
     ix->n_cu = prop.multiProcessorCount;
-    const size_t bytes = (size_t)n_rows * dim * (storage == ICREC_ROWS_BF16 ? 2 : 4);
+    const size_t bytes = (size_t)n_rows * dim * (rows16 ? 2 : 4);
     hipError_t e = hipMalloc(&ix->rows, bytes);
     if (e != hipSuccess) {
         delete ix;
@@ -927,12 +957,12 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
         return ICREC_ENOMEM;
     }
     const dim3 grid((unsigned)((n_rows + 3) / 4));
-    if (storage == ICREC_ROWS_BF16)
+    if (rows16)
         hipLaunchKernelGGL(normalize_rows_kernel<true>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
     else
         hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
     ICREC_HIP(hipGetLastError());
-    if (storage == ICREC_ROWS_F32_FILTER) {
+    if (with_planes) {
         const size_t n = (size_t)n_rows * dim;
         hipError_t e1 = hipMalloc(&ix->plane_hi, n * 2), e2 = hipMalloc(&ix->plane_lo, n * 2);
         if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -941,8 +971,12 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
             set_error("icrec_index_create: hipMalloc of the filter planes (2 x %zu bytes) failed", n * 2);
             return ICREC_ENOMEM;
         }
-        hipLaunchKernelGGL(split_queries_kernel, dim3(4096), dim3(256), 0, 0, static_cast<const float*>(ix->rows), n,
-                           ix->plane_hi, ix->plane_lo, (int*)nullptr);
+        if (rows16)  // planes of the ROUNDED rows: the filter then approximates exactly what the exact pass computes
+            hipLaunchKernelGGL(split_queries_kernel<true>, dim3(4096), dim3(256), 0, 0, (const void*)ix->rows, n, ix->plane_hi,
+                               ix->plane_lo, (int*)nullptr);
+        else
+            hipLaunchKernelGGL(split_queries_kernel<false>, dim3(4096), dim3(256), 0, 0, (const void*)ix->rows, n, ix->plane_hi,
+                               ix->plane_lo, (int*)nullptr);
         ICREC_HIP(hipGetLastError());
     }
     ICREC_HIP(hipStreamSynchronize(0));
@@ -974,7 +1008,7 @@ int icrec_index_export(const icrec_index* h, float* rows_dev, void* stream) {
     const Index* ix = reinterpret_cast<const Index*>(h);
     ICREC_REQUIRE(ix && rows_dev, "icrec_index_export: NULL argument");
     const int64_t n = ix->n_rows * ix->dim;
-    if (ix->storage == ICREC_ROWS_BF16) {
+    if (rows_are_bf16(ix)) {
         ICREC_HIP(hipSetDevice(ix->device));
         hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            static_cast<const uint16_t*>(ix->rows), rows_dev, n);

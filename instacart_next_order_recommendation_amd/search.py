@@ -45,7 +45,7 @@ def exclusion_csr(exclude: Optional[Sequence[Iterable[int]]], n_queries: int, de
     return idx, torch.from_numpy(off).to(device)
 
 
-ROW_STORAGE = {"f32": 0, "bf16": 1, "f32+filter": 2}  # ICREC_ROWS_* in include/icrec.h
+ROW_STORAGE = {"f32": 0, "bf16": 1, "f32+filter": 2, "bf16+filter": 3}  # ICREC_ROWS_* in include/icrec.h
 
 
 class DeviceIndex:

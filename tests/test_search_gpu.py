@@ -379,3 +379,21 @@ def test_filter_full_catalog_batch(torch_cuda):
     _native.timing_enable(False)
     fb2, _ = _native.timing_query(4)
     assert fb2 > 3 * fallback_ms, (fb2, fallback_ms)
+
+
+@pytest.mark.parametrize("nq,k,n", [(256, 20, 3000), (300, 50, 5000)])
+def test_bf16_filter_index_is_bit_identical_to_bf16_exact(torch_cuda, nq, k, n):
+    """ICREC_ROWS_BF16_FILTER: filter planes built from the ROUNDED rows, verification and fallback on the bf16 rows
+    themselves — same bits as storage="bf16" and as the oracle's bf16 search, incl. a duplicate-row fallback."""
+    rng = np.random.default_rng(nq + k)
+    P = rng.standard_normal((n, 384)).astype(np.float32)
+    P[rng.choice(n, 200, replace=False)] = P[1]  # 200 identical rows: some queries cannot be proven
+    q = rng.standard_normal((nq, 384)).astype(np.float32)
+    q[: nq // 4] = P[1] + 0.05 * q[: nq // 4]
+    excl = [rng.choice(n, size=rng.integers(0, 30), replace=False).tolist() for _ in range(nq)]
+    want_i, want_s = _oracle().search(q, P, k, excl, storage="bf16")
+    ix = _search_mod().DeviceIndex(P, storage="bf16+filter")
+    idx, sc = ix.search(q, k, excl)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want_s)
+    np.testing.assert_array_equal(ix.export().cpu().numpy(), _oracle().round_bf16(_oracle().normalize_rows(P)))

@@ -13,7 +13,7 @@ from instacart_next_order_recommendation_amd.search import DeviceIndex
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, nargs="+", default=[49688, 2_000_000])
-ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f32+filter"])
+ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f32+filter", "bf16+filter"])
 ap.add_argument("--queries", type=int, nargs="+", default=[1, 8, 32, 64, 256, 1024])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -26,7 +26,7 @@ for n in args.rows:
         m = min(1 << 18, n - s)
         rows[s:s + m] = centres[torch.randint(0, 200, (m,), device=dev, generator=g)] + 0.35 * torch.randn(m, 384, device=dev, generator=g)
     ix = DeviceIndex(rows, dev, storage=args.storage)
-    esz = 2 if args.storage == "bf16" else 4
+    esz = 2 if args.storage.startswith("bf16") else 4
     del rows
     for q in args.queries:
         qv = centres[torch.randint(0, 200, (q,), device=dev, generator=g)] + 0.35 * torch.randn(q, 384, device=dev, generator=g)
