@@ -58,6 +58,7 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
     catalog, as the reference does on every call) + full argsort + top-20 for each of them."""
     from oracle import oracle
 
+    oracle.set_threads(oracle.usable_cpus())  # the container's CPU quota, not the host's core count
     cfg = oracle.make_cfg(vocab_size=shape.vocab_size, n_normalize=shape.n_normalize)
     cu_s = cu[: n_sample + 1]
     ids_s = ids[: cu_s[-1]]
@@ -78,7 +79,8 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
             "single_request_p50_ms": float(np.median(one)),
             "sample": f"{n_sample} of the step's contexts ({int(cu_s[-1])} tokens): oracle encode {t1 - t0:.2f}s + "
                       f"cos_sim/argsort/top-{TOP_K} over {catalog.shape[0]} rows {t2 - t1:.2f}s (OpenMP C port, "
-                      f"batched; the reference serves one request at a time)"}
+                      f"batched, threads = the container's CPU quota of {oracle.threads()} on a {os.cpu_count()}-CPU host; "
+                      f"the reference serves one request at a time: single_request_p50_ms)"}
 
 
 def roofline(mode: str, achieved: float, n: int, ms: float, flops: float) -> dict:

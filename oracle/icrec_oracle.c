@@ -415,6 +415,16 @@ ORACLE_API void icrec_oracle_merge(const int64_t* idx, const float* score, int n
     }
 }
 
+/* Cap the OpenMP team (bench.py sizes it to the container's CPU quota: oversubscribing a 16-CPU cgroup with
+ * 128 threads makes the baseline 2x slower batched and 8x slower per request). */
+ORACLE_API void icrec_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int icrec_oracle_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

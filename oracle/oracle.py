@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
         L.icrec_oracle_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p]
         L.icrec_oracle_threads.restype = C.c_int
+        L.icrec_oracle_set_threads.restype = None
+        L.icrec_oracle_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -167,3 +169,28 @@ def merge(idx: np.ndarray, score: np.ndarray):
 
 def threads() -> int:
     return int(lib().icrec_oracle_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().icrec_oracle_set_threads(int(n))
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: min(affinity mask, cgroup v2/v1 CPU quota)."""
+    import math
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    return n
