@@ -328,7 +328,7 @@ def main() -> None:
         wall = time.perf_counter() - t_a
         text_path = {"qps": args.batch * reps / wall, "ms_per_step": wall / reps * 1e3,
                      "tokenize_ms_per_step": tok_s / reps * 1e3, "tokens_per_step": n_tok_text,
-                     "host_threads": os.cpu_count(),
+                     "host_threads": "min(CPU quota, texts/64) worker threads inside icrec_tokenize", "host_cpus_visible": os.cpu_count(),
                      "note": "synthetic user-context STRINGS -> native WordPiece on the host -> H2D -> encode -> "
                              "search -> D2H, strictly serial (no overlap of tokenisation with GPU work)"}
 

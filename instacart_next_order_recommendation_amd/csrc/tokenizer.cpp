@@ -12,6 +12,7 @@
 //   template         [CLS] tokens [SEP], truncated to max_len (tokens cut on the right)
 // Unicode data: unicode_tables.h (generated from Python's unicodedata).  Known difference from the Rust
 // crate: unassigned code points are kept (-> [UNK]) instead of being dropped as "other".
+#include <sched.h>
 #include <string.h>
 
 #include <algorithm>
@@ -242,6 +243,25 @@ int icrec_tokenizer_create(const char* vocab_path, int do_lower_case, int max_le
     return ICREC_OK;
 }
 
+// CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a 16-CPU container on a
+// 256-CPU host reports 256 hardware threads; spawning that many only adds scheduling overhead).
+static int usable_cpus() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1 << 30, CPU_COUNT(&set));
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string quota;
+    long long period = 0;
+    if (f && (f >> quota >> period) && quota != "max" && period > 0) {
+        const long long q = atoll(quota.c_str());
+        if (q > 0) n = std::min(n, (int)((q + period - 1) / period));
+    }
+    cached = std::max(1, n);
+    return cached;
+}
+
 int icrec_tokenizer_destroy(icrec_tokenizer* t) { delete t; return ICREC_OK; }
 
 int32_t icrec_tokenizer_vocab_size(const icrec_tokenizer* t) { return t ? (int32_t)t->vocab.size() : 0; }
@@ -249,7 +269,7 @@ int32_t icrec_tokenizer_vocab_size(const icrec_tokenizer* t) { return t ? (int32
 int icrec_tokenize(const icrec_tokenizer* t, const char* const* texts, int32_t n, int32_t* out_ids, int64_t cap,
                    int32_t* out_cu, int32_t n_threads) {
     if (!t || !texts || !out_cu || n < 0 || (cap > 0 && !out_ids)) { set_error("icrec_tokenize: bad argument"); return ICREC_EINVAL; }
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : usable_cpus();
     nt = std::max(1, std::min(nt, std::max(1, n / 64)));  // below ~64 texts per thread the spawn costs more
     std::vector<std::vector<int32_t>> ids(nt), lens(nt);
     auto work = [&](int w) {
