@@ -112,6 +112,40 @@ __device__ __forceinline__ void merge_queue(u64* list, const u64* queue, int n, 
     if (lane + 64 < k && p1 < k) list[p1] = e1;
 }
 
+// Two queries per call for k <= 32 and queues of <= 32 slots: lanes 0-31 merge query qa, lanes 32-63 query qb
+// (nb == 0: no partner).  Same ranking rule as merge_queue; the ballot's two halves serve the two queries.  Also
+// publishes the new thresholds and clears the queue counters.
+__device__ __forceinline__ void merge_queue2(u64* list, const u64* queue, int qcap, int qa, int na, int qb, int nb, int k,
+                                             int lane, u64* thr, int* cnt) {
+    const int half = lane >> 5, l = lane & 31;
+    const int q = half ? qb : qa, n = half ? nb : na;
+    u64* lst = list + (size_t)q * k;
+    const u64 c = l < n ? queue[q * qcap + l] : 0ull;
+    const u64 e0 = l < k ? lst[l] : 0ull;
+    const uint32_t c_lo = (uint32_t)c, c_hi = (uint32_t)(c >> 32);
+    int rc = 0, r0 = 0, lc = 0;
+    const int nmax = na > nb ? na : nb;
+    for (int i = 0; i < nmax; ++i) {
+        const u64 ca = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)c_hi, i) << 32) |
+                       (u64)(uint32_t)__builtin_amdgcn_readlane((int)c_lo, i);
+        const u64 cb = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)c_hi, 32 + i) << 32) |
+                       (u64)(uint32_t)__builtin_amdgcn_readlane((int)c_lo, 32 + i);
+        const u64 ci = half ? cb : ca;  // 0 past this query's own count: compares false everywhere
+        rc += ci > c;
+        r0 += ci > e0;
+        const unsigned long long m = __ballot(e0 > ci);
+        const int better = half ? __popc((unsigned)(m >> 32)) : __popc((unsigned)m);
+        lc = l == i ? better : lc;
+    }
+    if (n > 0) {
+        const int pc = rc + lc, p0 = l + r0;
+        // all reads above are complete (their values are consumed) before any lane writes
+        if (l < n && pc < k) lst[pc] = c;
+        if (l < k && p0 < k) lst[p0] = e0;
+        if (l == 0) { thr[q] = lst[k - 1]; cnt[q] = 0; }
+    }
+}
+
 // Grid: n_chunks * n_qtiles blocks (XCD-remapped).  Block (chunk, qtile) scores catalog row
 // tiles [chunk*tiles_per_chunk, ...) against query tile qtile and keeps, per query, the k best
 // (score, row) seen, then writes them (sorted, as keys) to partial[chunk][query][0..k).
@@ -289,11 +323,30 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
                 wg_cold = flags[2] != 0;
                 if (tid == 0) flags[(round + 1) & 1] = 0;
                 const bool force = wg_cold || last_tile;
-                // each wave merges the queues of its share of the queries
-                for (int q = wave; q < Cfg::BN; q += Cfg::THREADS / 64) {
-                    const int c = cnt[q];
-                    if (c > 0 && (force || 2 * c >= QCAP)) {
-                        merge_queue(list + (size_t)q * k, queue + q * QCAP, c < QCAP ? c : QCAP, k, lane);
+                // each wave merges the queues of its share of the queries (query wave + NW * t is polled by lane t:
+                // one LDS read for all of them instead of one dependent read per query)
+                constexpr int NW = Cfg::THREADS / 64, QPW = Cfg::BN / NW;
+                static_assert(QPW <= 64, "one polling lane per query");
+                int myc = lane < QPW ? cnt[wave + NW * lane] : 0;
+                myc = myc < QCAP ? myc : QCAP;
+                unsigned long long need = __ballot(myc > 0 && (force || 2 * myc >= QCAP));
+                if (QCAP <= 32 && k <= 32) {
+                    while (need) {  // two queries per merge call
+                        const int ta = __builtin_ctzll(need);
+                        need &= need - 1;
+                        const int tb = need ? __builtin_ctzll(need) : -1;
+                        if (tb >= 0) need &= need - 1;
+                        const int na = __builtin_amdgcn_readlane(myc, ta);
+                        const int nb = tb >= 0 ? __builtin_amdgcn_readlane(myc, tb) : 0;
+                        merge_queue2(list, queue, QCAP, wave + NW * ta, na, wave + NW * (tb >= 0 ? tb : ta), nb, k, lane, thr,
+                                     cnt);
+                    }
+                } else {
+                    while (need) {
+                        const int t = __builtin_ctzll(need);
+                        need &= need - 1;
+                        const int q = wave + NW * t;
+                        merge_queue(list + (size_t)q * k, queue + q * QCAP, __builtin_amdgcn_readlane(myc, t), k, lane);
                         if (lane == 0) { thr[q] = list[(size_t)q * k + k - 1]; cnt[q] = 0; }
                     }
                 }
