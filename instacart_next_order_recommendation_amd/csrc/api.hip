@@ -62,7 +62,7 @@ extern "C" {
 
 const char* icrec_last_error(void) { return g_err; }
 
-const char* icrec_version(void) { return "icrec 0.1 (gfx950, fp32 MFMA)"; }
+const char* icrec_version(void) { return "icrec 0.1 (gfx950; exact-f32 and f16x3 MFMA)"; }
 
 int icrec_timing_enable(int on) {
     g_timing = on != 0;
