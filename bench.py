@@ -75,8 +75,15 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
         e1 = oracle.encode(weights, cfg, ids[cu[r]:cu[r + 1]], np.array([0, cu[r + 1] - cu[r]], np.int32))
         oracle.search(e1, catalog, TOP_K, None)
         one.append((time.perf_counter() - a) * 1e3)
+    c1 = []  # BASELINE configs[0]: one query against a 1,000-product subset, CPU only
+    for r in range(5):
+        a = time.perf_counter()
+        e1 = oracle.encode(weights, cfg, ids[cu[r]:cu[r + 1]], np.array([0, cu[r + 1] - cu[r]], np.int32))
+        oracle.search(e1, catalog[:1000], TOP_K, None)
+        c1.append((time.perf_counter() - a) * 1e3)
     return {"value": n_sample / (t2 - t0), "unit": "queries/s", "cores": oracle.threads(), "kind": "port",
             "single_request_p50_ms": float(np.median(one)),
+            "configs0_single_query_vs_1k_products_p50_ms": float(np.median(c1)),
             "sample": f"{n_sample} of the step's contexts ({int(cu_s[-1])} tokens): oracle encode {t1 - t0:.2f}s + "
                       f"cos_sim/argsort/top-{TOP_K} over {catalog.shape[0]} rows {t2 - t1:.2f}s (OpenMP C port, "
                       f"batched, threads = the container's CPU quota of {oracle.threads()} on a {os.cpu_count()}-CPU host; "
