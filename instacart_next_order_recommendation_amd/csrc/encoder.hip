@@ -170,7 +170,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
 // (the FFN-down GEMM's A operand) and never as fp32.
 // DEPTH > 1: the small-M (latency-bound) form with DEPTH slabs in flight, see tile_gemm_h_deep.
 template <class Cfg, int EPI, int DEPTH = 1>
-__global__ __launch_bounds__(Cfg::THREADS) void linear_x3_kernel(
+__global__ __launch_bounds__(Cfg::THREADS, (DEPTH == 1 && EPI == 0) ? 4 : 1) void linear_x3_kernel(  // EPI 0 needs the 4-waves-per-SIMD hint to stay at 128 VGPRs (two workgroups per CU); EPI 1 fits without it and schedules better
     const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int M, int K, const _Float16* __restrict__ Wh,
     const _Float16* __restrict__ Wl, int N, const float* __restrict__ bias, float* __restrict__ out,
     _Float16* __restrict__ oh, _Float16* __restrict__ ol, int n_tiles_n) {
@@ -183,28 +183,39 @@ __global__ __launch_bounds__(Cfg::THREADS) void linear_x3_kernel(
     f32x16 acc0[Cfg::TM][Cfg::TN], acc1[Cfg::TM][Cfg::TN];
     if (DEPTH > 1) tile_gemm_h_deep<Cfg, DEPTH>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
     else tile_gemm_h<Cfg>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
+    // epilogue addressing: one 64-bit base per workgroup, 32-bit offsets inside the tile (<= 128 x N elements)
+    const int rows_left = (int)(M - m0 < Cfg::BM ? M - m0 : Cfg::BM), cols_left = (int)(N - n0 < Cfg::BN ? N - n0 : Cfg::BN);
+    const size_t tile_base = (size_t)m0 * N + (size_t)n0;
+    float* const out_t = EPI == 1 ? nullptr : out + tile_base;
+    _Float16* const oh_t = EPI == 1 ? oh + tile_base : nullptr;
+    _Float16* const ol_t = EPI == 1 ? ol + tile_base : nullptr;
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
-        const int64_t col = n0 + (wn * Cfg::TN + j) * 32 + (lane & 31);
-        const float bv = col < N ? bias[col] : 0.0f;
+        const int lcol = (wn * Cfg::TN + j) * 32 + (lane & 31);
+        const bool col_ok = lcol < cols_left;
+        const float bv = col_ok ? bias[n0 + lcol] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
+        for (int i = 0; i < Cfg::TM; ++i) {
+            const int lrow0 = (wm * Cfg::TM + i) * 32 + 4 * (lane >> 5);
+            const int off0 = lrow0 * N + lcol;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = m0 + (wm * Cfg::TM + i) * 32 + acc_row(e, lane);
-                if (row < M && col < N) {
+                const int dr = (e & 3) + 8 * (e >> 2);  // acc_row(e, lane) = dr + 4 * (lane >> 5)
+                if (col_ok && lrow0 + dr < rows_left) {
+                    const int off = off0 + dr * N;
                     float v = fmaf(acc1[i][j][e], LO_UNSCALE, acc0[i][j][e]) + bv;
                     if (EPI == 1) {
                         v = gelu_erf_fast(v);
                         _Float16 hi, lo;
                         split_f16(v, hi, lo);
-                        oh[row * N + col] = hi;
-                        ol[row * N + col] = lo;
+                        oh_t[off] = hi;
+                        ol_t[off] = lo;
                     } else {
-                        out[row * N + col] = v;
+                        out_t[off] = v;
                     }
                 }
             }
+        }
     }
 }
 
