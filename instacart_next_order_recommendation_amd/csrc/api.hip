@@ -4,6 +4,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -17,6 +19,19 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+static std::mutex g_attr_mu;
+static std::set<std::pair<const void*, int>> g_attr_done;
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    int dev = 0;
+    ICREC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (g_attr_done.count({kernel, dev})) return ICREC_OK;
+    ICREC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_attr_done.insert({kernel, dev});
+    return ICREC_OK;
 }
 
 static bool g_timing = false;

@@ -30,6 +30,11 @@ void set_error(const char* fmt, ...);
         }                                      \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device function attribute: set it once per (kernel,
+// device) under a lock (a second device in the same process, or two threads racing on the first launch, would
+// otherwise launch with the 64 KB default and fail).  Uses the calling thread's current device.
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // hipEvent-based per-kernel timing on the launch stream (bench.py's roofline leg).
 struct TimingSlot {
     double total_ms = 0.0;

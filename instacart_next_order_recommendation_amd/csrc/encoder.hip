@@ -707,24 +707,14 @@ static int launch_linear_x3(const _Float16* Ah, const _Float16* Al, int M, int K
         // prefetch depth 1-6, 64x64/4 waves of ONE 32x32 tile 12 us): use the smallest per-wave tile and many
         // workgroups.  Per-output arithmetic is unchanged, so results are bit-identical to the batch kernel.
         auto kern = linear_x3_kernel<GemmX3Small, EPI, X3_SMALL_DEPTH>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)SmemH<GemmX3Small>::BYTES));
-            attr_set = true;
-        }
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)SmemH<GemmX3Small>::BYTES)) return rc_;
         const int mt = (M + GemmX3Small::BM - 1) / GemmX3Small::BM, nt = (N + GemmX3Small::BN - 1) / GemmX3Small::BN;
         hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(GemmX3Small::THREADS), SmemH<GemmX3Small>::BYTES, st, Ah, Al, M, K,
                            Wh, Wl, N, bias, out, oh, ol, nt);
         return ICREC_OK;
     }
     auto kern = linear_x3_kernel<GemmX3, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)SmemH<GemmX3>::BYTES));
-        attr_set = true;
-    }
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)SmemH<GemmX3>::BYTES)) return rc_;
     const int mt = (M + GemmX3::BM - 1) / GemmX3::BM, nt = (N + GemmX3::BN - 1) / GemmX3::BN;
     hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(GemmX3::THREADS), SmemH<GemmX3>::BYTES, st, Ah, Al, M, K, Wh, Wl, N,
                        bias, out, oh, ol, nt);

@@ -801,12 +801,7 @@ static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q,
                          const int32_t* eo, u64* partial, float* scores_out, hipStream_t st,
                          const int* run_flag = nullptr) {
     auto kern = search_kernel<Cfg, EMIT, P16 ? 1 : 0>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024));
-        attr_set = true;
-    }
+    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc_;
     const int grid = p.n_chunks * p.n_qtiles;
     {
         ScopedTimer tm(run_flag == nullptr ? T_SEARCH_KERNEL : T_SEARCH_FALLBACK, st);  // the guarded pass has its own slot
@@ -877,12 +872,7 @@ static int run_search_filtered(Index* ix, const FilterPlan& f, const Plan& ex, c
                        dim3(256), 0, st, (const void*)qn, nq, qh, ql, flag);
     {
         auto kern = search_kernel<CfgFilter, false, 2>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            ICREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          160 * 1024));
-            attr_set = true;
-        }
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc_;
         ScopedTimer tm(T_SEARCH_KERNEL, st);
         hipLaunchKernelGGL(kern, dim3(f.n_chunks * f.n_qtiles), dim3(CfgFilter::THREADS), f.smem, st,
                            (const void*)ix->plane_hi, (const void*)ix->plane_lo, ix->n_rows, ix->dim, (const void*)qh,
