@@ -80,6 +80,15 @@ class SingleRequestPath:
     def __init__(self, encoder: DeviceEncoder, index: DeviceIndex):
         self.encoder, self.index = encoder, index
         self._graphs: dict[tuple[int, int], _Captured] = {}
+        self._handles = self._handle_key()
+
+    def _handle_key(self):
+        return (self.encoder._h.value if self.encoder._h else None, self.index._h.value if self.index._h else None)
+
+    def invalidate(self) -> None:
+        """Drop every captured graph (they bake raw handles, buffers and workspaces)."""
+        self._graphs.clear()
+        self._handles = self._handle_key()
 
     def supports(self, n_tokens: int, k: int, n_excluded: int) -> bool:
         return 1 <= n_tokens <= BUCKETS[-1] and n_excluded <= MAX_EXCLUDED and k <= self.index.n_rows
@@ -90,6 +99,10 @@ class SingleRequestPath:
         ex = sorted(set(int(r) for r in excluded_rows)) if excluded_rows else []
         if not self.supports(n, k, len(ex)):
             raise ValueError("request outside the captured fast path")
+        if self._handle_key() != self._handles:  # encoder / index re-created under us (close() + new handle)
+            self.invalidate()
+        if self._handles[0] is None or self._handles[1] is None:
+            raise _native.IcrecError("SingleRequestPath: encoder or index handle is closed")
         bucket = next(b for b in BUCKETS if n <= b)
         c = self._graphs.get((bucket, k))
         if c is None:

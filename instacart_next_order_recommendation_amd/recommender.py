@@ -261,6 +261,9 @@ class Recommender:
         """Top-k (product_id, score) by cosine similarity, best first (reference :206-225).
         One query = one hipGraph replay (fastpath.py) when ICREC_USE_GRAPH is not "0"."""
         if self._fast is not None:
+            if self._fast.index is not self._index or self._fast.encoder is not self.model.encoder:
+                # a captured graph bakes the index / encoder handles: a rebuilt index or model drops every graph
+                self._fast = type(self._fast)(self.model.encoder, self._index)
             top_k = max(int(top_k), 1)
             ids = self.model.tokenizer([query])[0]
             ex = self._excluded_rows(exclude_product_ids)
