@@ -156,6 +156,8 @@ ICREC_API int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32
 ICREC_API int icrec_index_destroy(icrec_index* idx);
 ICREC_API int64_t icrec_index_rows(const icrec_index* idx);
 ICREC_API int32_t icrec_index_storage(const icrec_index* idx); /* ICREC_ROWS_* (-1: NULL handle) */
+ICREC_API int32_t icrec_index_dim(const icrec_index* idx);     /* embedding width (0: NULL handle)  */
+ICREC_API int32_t icrec_index_device(const icrec_index* idx);  /* HIP device ordinal (-1: NULL)     */
 
 /* Copy the normalised rows back out (row-major fp32 [n_rows, dim]; bf16 storage is
  * widened exactly); used by the parity tests and by EmbeddingIndex.save.     */
@@ -213,6 +215,45 @@ ICREC_API int icrec_scores(icrec_index* idx, const float* q_dev, int32_t n_queri
  * (torch.nn.functional.normalize(p=2, dim=1) as used by cos_sim.)            */
 ICREC_API int icrec_normalize_rows(const float* x_dev, float* out_dev, int64_t n_rows,
                          int32_t dim, float eps, int device, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU exchange (new design, the reference has none:      */
+/* serve_recommendations.py:172-181 only picks a device).  One process per    */
+/* GPU; the catalog is row-sharded (each rank's icrec_index carries its       */
+/* row_offset), queries are data-parallel.  The collectives are RCCL          */
+/* all-gathers over xGMI, issued on the caller's stream from inside the       */
+/* library (librccl.so.1 is bound with dlopen on first use).                  */
+/* ------------------------------------------------------------------------- */
+typedef struct icrec_comm icrec_comm;
+#define ICREC_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+/* Rank 0 creates the rendezvous id (ncclGetUniqueId) into id_out[ICREC_COMM_ID_BYTES] (host memory) and
+ * hands the bytes to every other rank by any out-of-band channel (file, socket, MPI, torch store). */
+ICREC_API int icrec_comm_unique_id(void* id_out);
+/* Collective over all `world` ranks: ncclCommInitRank on `device`.  world == 1 with unique_id == NULL makes a
+ * communicator that exchanges nothing (icrec_search_sharded then equals icrec_search). */
+ICREC_API int icrec_comm_init(const void* unique_id, int rank, int world, int device, icrec_comm** out);
+ICREC_API int icrec_comm_destroy(icrec_comm* comm);
+ICREC_API int32_t icrec_comm_rank(const icrec_comm* comm);
+ICREC_API int32_t icrec_comm_world(const icrec_comm* comm);
+
+ICREC_API size_t icrec_search_sharded_workspace_bytes(const icrec_index* idx, const icrec_comm* comm,
+                                            int32_t n_local_queries, int32_t k);
+/* Collective sharded top-k: every rank passes ITS n_local query embeddings (the same n_local on every rank)
+ * and gets the global result for all Q = world * n_local queries, in rank-major order:
+ *     ncclAllGather(q_local) -> icrec_search_partial over this rank's shard ->
+ *     ncclAllGather(partial keys) -> icrec_merge_topk
+ *   q_local_dev   float[n_local, dim]
+ *   excl_idx_dev / excl_off_dev  CSR of LOCAL row numbers (this shard's rows) to skip for each of the Q
+ *                                gathered queries (int32[Q+1] offsets), or NULL
+ *   out_idx_dev   int64[Q, k] GLOBAL rows (row_offset + local row), -1 pads;  out_score_dev float[Q, k]
+ * The result is bit-identical on every rank and to icrec_search over the unsharded catalog: the union of the
+ * per-shard top-k lists contains the global top-k and the (score desc, row asc) order is total. */
+ICREC_API int icrec_search_sharded(icrec_index* idx, icrec_comm* comm, const float* q_local_dev,
+                         int32_t n_local_queries, int32_t k,
+                         const int32_t* excl_idx_dev, const int32_t* excl_off_dev,
+                         int64_t* out_idx_dev, float* out_score_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Host tokenizer: the WordPiece stage of SentenceTransformer.encode           */

@@ -14,6 +14,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libicrec.so"
 
 ICREC_MAX_K = 128
+COMM_ID_BYTES = 128
 GEMM_F32, GEMM_F16X3 = 0, 1
 GEMM_MODES = {"f32": GEMM_F32, "f16x3": GEMM_F16X3}
 
@@ -22,7 +23,9 @@ EXPORTS = [
     "icrec_encoder_weight_count", "icrec_encoder_create", "icrec_encoder_destroy",
     "icrec_encode_workspace_bytes", "icrec_encode",
     "icrec_index_create", "icrec_index_create_ex", "icrec_index_destroy", "icrec_index_rows", "icrec_index_storage",
-    "icrec_index_export",
+    "icrec_index_export", "icrec_index_dim", "icrec_index_device",
+    "icrec_comm_unique_id", "icrec_comm_init", "icrec_comm_destroy", "icrec_comm_rank", "icrec_comm_world",
+    "icrec_search_sharded_workspace_bytes", "icrec_search_sharded",
     "icrec_search_workspace_bytes", "icrec_search", "icrec_search_partial", "icrec_merge_topk",
     "icrec_scores", "icrec_normalize_rows",
     "icrec_tokenizer_create", "icrec_tokenizer_destroy", "icrec_tokenizer_vocab_size", "icrec_tokenize",
@@ -81,6 +84,15 @@ def lib() -> C.CDLL:
         "icrec_index_create": (C.c_int, [vp, i64, i32, i64, C.c_int, C.POINTER(vp)]),
         "icrec_index_create_ex": (C.c_int, [vp, i64, i32, i64, C.c_int, i32, C.POINTER(vp)]),
         "icrec_index_storage": (i32, [vp]),
+        "icrec_index_dim": (i32, [vp]),
+        "icrec_index_device": (i32, [vp]),
+        "icrec_comm_unique_id": (C.c_int, [vp]),
+        "icrec_comm_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+        "icrec_comm_destroy": (C.c_int, [vp]),
+        "icrec_comm_rank": (i32, [vp]),
+        "icrec_comm_world": (i32, [vp]),
+        "icrec_search_sharded_workspace_bytes": (sz, [vp, vp, i32, i32]),
+        "icrec_search_sharded": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
         "icrec_index_destroy": (C.c_int, [vp]),
         "icrec_index_rows": (i64, [vp]),
         "icrec_index_export": (C.c_int, [vp, vp, vp]),

@@ -1033,6 +1033,8 @@ int icrec_index_create(const float* rows_dev, int64_t n_rows, int32_t dim, int64
 }
 
 int32_t icrec_index_storage(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->storage : -1; }
+int32_t icrec_index_dim(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->dim : 0; }
+int32_t icrec_index_device(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->device : -1; }
 
 int icrec_index_destroy(icrec_index* h) {
     Index* ix = reinterpret_cast<Index*>(h);

@@ -12,12 +12,18 @@ the query batch, then:
 The union of per-shard top-k lists contains the global top-k and the (score desc, row asc)
 order is total, so the merged result is bit-identical to a single-GPU search.
 
-The reference has no distributed code at all; this is new design.  The class
-is backend-agnostic so that the collective plumbing can be exercised with gloo on CPU in
-tests (with the oracle standing in for the kernels); the product backend is HipShardBackend.
+The reference has no distributed code at all; this is new design.
+
+Product path: `NativeComm` (an RCCL communicator created by libicrec: icrec_comm_init) +
+`ShardedSearch(..., comm=NativeComm)`: ONE C call, icrec_search_sharded, runs both all-gathers, the
+shard-local search and the merge on the caller's stream — torch.distributed is used only to hand the
+128-byte rendezvous id to the other ranks.  Without a `comm` the class falls back to collectives issued
+through torch.distributed on the same C kernels; that form is backend-agnostic so that the row arithmetic
+can be exercised with gloo on CPU in tests (with the oracle standing in for the kernels).
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Iterable, Optional, Protocol, Sequence
 
 import torch
@@ -55,15 +61,106 @@ class HipShardBackend:
         return merge_topk(keys, k)
 
 
+class NativeComm:
+    """An RCCL communicator owned by libicrec (include/icrec.h: icrec_comm_*): one per process/GPU."""
+
+    def __init__(self, rank: int, world: int, device, unique_id: Optional[bytes] = None):
+        from . import _native
+
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _native.IcrecError("NativeComm needs a CUDA/HIP device")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.rank, self.world = int(rank), int(world)
+        if unique_id is not None and len(unique_id) != _native.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {_native.COMM_ID_BYTES} bytes")
+        buf = C.create_string_buffer(unique_id, _native.COMM_ID_BYTES) if unique_id is not None else None
+        h = C.c_void_p()
+        _native.check(_native.lib().icrec_comm_init(buf, self.rank, self.world, self.device.index, C.byref(h)),
+                      "icrec_comm_init")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """ncclGetUniqueId (call on ONE rank, ship the bytes to the others)."""
+        from . import _native
+
+        buf = C.create_string_buffer(_native.COMM_ID_BYTES)
+        _native.check(_native.lib().icrec_comm_unique_id(buf), "icrec_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, device, group=None) -> "NativeComm":
+        """Bootstrap over an initialised torch.distributed group: rank 0 draws the id, a 128-byte broadcast
+        delivers it (the only use of torch.distributed on the product path)."""
+        if not dist.is_initialized():
+            return cls(0, 1, device, None)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if world == 1:
+            return cls(0, 1, device, None)
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8, device=torch.device(device) if on_gpu else "cpu")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, device, bytes(t.cpu().numpy().tobytes()))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            from . import _native
+
+            _native.lib().icrec_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedSearch:
     """Collective top-k over a row-sharded catalog.  Every rank calls `search` with ITS slice of
     the query embeddings (equal slice sizes on all ranks); every rank gets the full result."""
 
-    def __init__(self, backend: ShardBackend, row_lo: int, row_hi: int, group=None):
+    def __init__(self, backend: ShardBackend, row_lo: int, row_hi: int, group=None,
+                 comm: Optional[NativeComm] = None):
         self.backend = backend
         self.row_lo, self.row_hi = int(row_lo), int(row_hi)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm = comm
+        if comm is not None:
+            if not isinstance(backend, HipShardBackend):
+                raise TypeError("a NativeComm drives the HIP backend only")
+            self.world = comm.world
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._ws: Optional[torch.Tensor] = None
+
+    def _search_native(self, q_local: torch.Tensor, k: int, exclude_global):
+        """icrec_search_sharded: all-gather, shard-local search, all-gather, merge — one C call."""
+        from . import _native
+        from .search import exclusion_csr
+
+        ix = self.backend.index
+        q = q_local.to(device=ix.device, dtype=torch.float32).contiguous()
+        n_local = int(q.shape[0])
+        Q = n_local * self.world
+        ei, eo = exclusion_csr(self._local_exclusions(exclude_global), Q, ix.device) if exclude_global is not None \
+            else (None, None)
+        L = _native.lib()
+        need = int(L.icrec_search_sharded_workspace_bytes(ix._h, self.comm._h, n_local, k))
+        if need == 0:
+            raise _native.IcrecError(f"bad sharded search shape: n_local={n_local}, k={k}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ix.device)
+        idx = torch.empty((Q, k), dtype=torch.int64, device=ix.device)
+        sc = torch.empty((Q, k), dtype=torch.float32, device=ix.device)
+        P = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        st = C.c_void_p(torch.cuda.current_stream(ix.device).cuda_stream)
+        _native.check(L.icrec_search_sharded(ix._h, self.comm._h, P(q), n_local, k, P(ei), P(eo), P(idx), P(sc),
+                                             P(self._ws), self._ws.numel(), st), "icrec_search_sharded")
+        return idx, sc
 
     def _local_exclusions(self, exclude_global):
         if exclude_global is None:
@@ -88,6 +185,8 @@ class ShardedSearch:
     def search(self, q_local: torch.Tensor, k: int, exclude_global: Optional[Sequence[Iterable[int]]] = None):
         """q_local [Q/W, d] -> (idx int64 [Q, k] global rows, score float32 [Q, k]) on every rank.
         `exclude_global`: per query (all Q of them, in gathered order) GLOBAL row numbers."""
+        if self.comm is not None:
+            return self._search_native(q_local, k, exclude_global)
         q_all = self.gather_queries(q_local)
         keys = self.backend.search_partial(q_all, k, self._local_exclusions(exclude_global))
         if self.world == 1:

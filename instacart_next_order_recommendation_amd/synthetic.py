@@ -205,25 +205,29 @@ def synthetic_catalog(n: int = 49688, seed: int = 42) -> dict[str, str]:
     return out
 
 
-def synthetic_user_contexts(n: int, seed: int = 1234) -> list[str]:
+def synthetic_user_contexts(n: int, seed: int = 1234, max_items: int = 20, max_orders: int = 5,
+                            min_orders: int = 1, per_order: int = 6) -> list[str]:
     """"[+{d}d w{dow}h{hh}] n1, n2; [+..] ..." with 1-5 orders and <= 20 names
-    (prepare_instacart_sbert.py:233-258; configs/data_prep.yaml:10-11)."""
-    h = hash_u64(seed, 2, n * 64).reshape(n, 64)
+    (prepare_instacart_sbert.py:233-258; configs/data_prep.yaml:10-11) — about 65 WordPiece tokens each.
+    bench.py's text leg passes max_items=40, min_orders=5, max_orders=8, per_order=8: heavier users
+    whose contexts average ~128 tokens, the same workload size as its token-id batches."""
+    W = 64 if max_items <= 20 else 160
+    h = hash_u64(seed, 2, n * W).reshape(n, W)
     out = []
     for i in range(n):
-        n_orders = 1 + int(h[i, 0] % np.uint64(5))
-        left = 20
+        n_orders = min_orders + int(h[i, 0] % np.uint64(max_orders - min_orders + 1))
+        left = max_items
         segs = []
         c = 1
         for o in range(n_orders):
             if left <= 0:
                 break
             d, dow, hh = int(h[i, c] % np.uint64(31)), int(h[i, c + 1] % np.uint64(7)), int(h[i, c + 2] % np.uint64(24))
-            cnt = min(left, 1 + int(h[i, c + 3] % np.uint64(6)))
+            cnt = min(left, 1 + int(h[i, c + 3] % np.uint64(per_order)))
             c += 4
             names = []
             for _ in range(cnt):
-                a, b = int(h[i, c % 64] % np.uint64(len(_WORDS))), int(h[i, (c + 1) % 64] % np.uint64(len(_WORDS)))
+                a, b = int(h[i, c % W] % np.uint64(len(_WORDS))), int(h[i, (c + 1) % W] % np.uint64(len(_WORDS)))
                 names.append(f"{_WORDS[a].capitalize()} {_WORDS[b].capitalize()}")
                 c += 2
             left -= cnt

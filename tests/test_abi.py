@@ -81,3 +81,17 @@ def test_no_gpu_means_loud_failure(native):
         DeviceIndex(np.ones((4, 384), np.float32))
     with pytest.raises(native.IcrecError):
         DeviceIndex(np.ones((4, 384), np.float32), device="cpu")
+
+
+def test_comm_entry_points_validate_arguments(native):
+    """The exchange entry points reject bad arguments without touching a GPU."""
+    import ctypes as C
+
+    lib = native.lib()
+    h = C.c_void_p()
+    assert lib.icrec_comm_init(None, 3, 2, 0, C.byref(h)) == -1  # rank >= world
+    assert b"rank" in lib.icrec_last_error()
+    assert lib.icrec_comm_init(None, 0, 2, 0, C.byref(h)) == -1  # world > 1 needs the rendezvous id
+    assert lib.icrec_comm_world(None) == 0 and lib.icrec_comm_rank(None) == -1
+    assert lib.icrec_search_sharded_workspace_bytes(None, None, 4, 20) == 0
+    assert lib.icrec_index_dim(None) == 0 and lib.icrec_index_device(None) == -1

@@ -68,3 +68,38 @@ def test_bench_multi_rank_flow_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["rehearsal_not_a_measurement"]
     assert d["config"]["contexts_per_gpu_per_step"] == 64
+
+
+def test_native_rccl_world1_equals_plain_search():
+    """icrec_comm_init (a real ncclCommInitRank on one rank) + icrec_search_sharded: both ncclAllGathers run
+    on the stream and the result is bit-equal to icrec_search and to the oracle, exclusions included."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.sharded import HipShardBackend, NativeComm, ShardedSearch
+    from oracle import oracle
+
+    dev = torch.device("cuda:0")
+    P = syn.synthetic_embeddings(6211, 384, seed=1)   # one shard of configs[3] (49,688 / 8 rows)
+    q = syn.synthetic_embeddings(512, 384, seed=2)    # 4,096 / 8 queries
+    excl = [[(13 * i) % 6211, 5, 6210] if i % 3 == 0 else [] for i in range(512)]
+    comm = NativeComm(0, 1, dev, NativeComm.unique_id())
+    assert comm.world == 1 and comm.rank == 0
+    be = HipShardBackend(torch.from_numpy(P).to(dev), 0, dev)
+    ss = ShardedSearch(be, 0, 6211, comm=comm)
+    qd = torch.from_numpy(q).to(dev)
+    for ex in (None, excl):
+        idx, sc = ss.search(qd, 20, ex)
+        pi, ps = be.index.search(qd, 20, ex)
+        assert torch.equal(idx, pi) and torch.equal(sc, ps)
+        wi, ws = oracle.search(q, P, 20, ex)
+        np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+        np.testing.assert_array_equal(sc.cpu().numpy(), ws)
+    # a shard with a row offset: global rows come back
+    be2 = HipShardBackend(torch.from_numpy(P[1000:3000]).to(dev), 1000, dev)
+    ss2 = ShardedSearch(be2, 1000, 3000, comm=comm)
+    idx2, sc2 = ss2.search(qd[:64], 20, [[1500, 2999, 5]] * 64)
+    wi2, ws2 = oracle.search(q[:64], P[1000:3000], 20, [[500, 1999]] * 64)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), wi2 + 1000)
+    np.testing.assert_array_equal(sc2.cpu().numpy(), ws2)
+    comm.close()
