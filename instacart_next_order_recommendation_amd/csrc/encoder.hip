@@ -7,8 +7,11 @@
 //   /root/reference/src/inference/serve_recommendations.py:213, :246 (per-request query)
 // Arithmetic follows transformers/models/bert/modeling_bert.py (tf:) as cited per kernel,
 // and oracle/icrec_oracle.c reduction orders where a kernel says "oracle order".
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_x3.h"
+#include "wt_gemm.h"
 
 namespace icrec {
 
@@ -47,7 +50,7 @@ __device__ __forceinline__ void ln_row(float (&v)[H / 64], const float* __restri
         out[i] = y;
         if (SPLIT) {
             _Float16 hi, lo;
-            split_f16(y, hi, lo);
+            split_act(y, hi, lo);
             oh[i] = hi;
             ol[i] = lo;
         }
@@ -165,68 +168,277 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
     }
 }
 
-// Same layers on the f16 matrix cores with 3-term operand splitting (gemm_x3.h).  A and W arrive as
-// f16 hi/lo planes.  EPI 0: out_f32 = acc + bias.  EPI 1: erf-GELU, result written as hi/lo planes
-// (the FFN-down GEMM's A operand) and never as fp32.
-// DEPTH > 1: the small-M (latency-bound) form with DEPTH slabs in flight, see tile_gemm_h_deep.
-template <class Cfg, int EPI, int DEPTH = 1>
-__global__ __launch_bounds__(Cfg::THREADS, (DEPTH == 1 && EPI == 0) ? 4 : 1) void linear_x3_kernel(  // EPI 0 needs the 4-waves-per-SIMD hint to stay at 128 VGPRs (two workgroups per CU); EPI 1 fits without it and schedules better
-    const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int M, int K, const _Float16* __restrict__ Wh,
-    const _Float16* __restrict__ Wl, int N, const float* __restrict__ bias, float* __restrict__ out,
-    _Float16* __restrict__ oh, _Float16* __restrict__ ol, int n_tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid / n_tiles_n, nt = bid % n_tiles_n;
-    const int64_t m0 = (int64_t)mt * Cfg::BM, n0 = (int64_t)nt * Cfg::BN;
-    f32x16 acc0[Cfg::TM][Cfg::TN], acc1[Cfg::TM][Cfg::TN];
-    if (DEPTH > 1) tile_gemm_h_deep<Cfg, DEPTH>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
-    else tile_gemm_h<Cfg>(acc0, acc1, Ah, Al, m0, M, Wh, Wl, n0, N, K, reinterpret_cast<_Float16*>(smem_x3));
-    // epilogue addressing: one 64-bit base per workgroup, 32-bit offsets inside the tile (<= 128 x N elements)
-    const int rows_left = (int)(M - m0 < Cfg::BM ? M - m0 : Cfg::BM), cols_left = (int)(N - n0 < Cfg::BN ? N - n0 : Cfg::BN);
-    const size_t tile_base = (size_t)m0 * N + (size_t)n0;
-    float* const out_t = EPI == 1 ? nullptr : out + tile_base;
-    _Float16* const oh_t = EPI == 1 ? oh + tile_base : nullptr;
-    _Float16* const ol_t = EPI == 1 ? ol + tile_base : nullptr;
+// ---------------------------------------------------------------- f16x3 linear layers (wt_gemm.h)
+// out^T = W . X^T with the weights streamed straight from L2 into registers (packed fragment order) and the
+// token slab staged through LDS.  Block = 4 waves; wave q owns NTW 32-feature tiles x TTW 32-token tiles.
+//   EPI 0: out fp32 [T, N] = acc * 2^-14 + bias           (QKV; attention-out / FFN-down of small batches)
+//   EPI 1: erf-GELU (tf:336), result as f16 hi/lo planes   (FFN-up of small batches)
+// Each lane holds 4 consecutive features of one token per register group: 16-B (fp32) / 8-B (planes) stores.
+template <int NTW, int TTW, int D, int EPI>
+__global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __restrict__ Xh,
+                                                           const _Float16* __restrict__ Xl, int T, int K,
+                                                           const _Float16* __restrict__ Wp, int N,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           _Float16* __restrict__ oh, _Float16* __restrict__ ol,
+                                                           int n_blocks_n) {
+    __shared__ __attribute__((aligned(16))) char smem[XRing<TTW>::BYTES];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int mt = blockIdx.x / n_blocks_n, nb = blockIdx.x % n_blocks_n;
+    const int64_t m0 = (int64_t)mt * (32 * TTW);
+    const int nt0 = (nb * 4 + q) * NTW;
+    f32x16 acc[NTW][TTW];
+    wt_kloop<NTW, TTW, D>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-        const int lcol = (wn * Cfg::TN + j) * 32 + (lane & 31);
-        const bool col_ok = lcol < cols_left;
-        const float bv = col_ok ? bias[n0 + lcol] : 0.0f;
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) {
-            const int lrow0 = (wm * Cfg::TM + i) * 32 + 4 * (lane >> 5);
-            const int off0 = lrow0 * N + lcol;
+        for (int g = 0; g < 4; ++g) {
+            const int feat = (nt0 + i) * 32 + 8 * g + 4 * h;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dr = (e & 3) + 8 * (e >> 2);  // acc_row(e, lane) = dr + 4 * (lane >> 5)
-                if (col_ok && lrow0 + dr < rows_left) {
-                    const int off = off0 + dr * N;
-                    float v = fmaf(acc1[i][j][e], LO_UNSCALE, acc0[i][j][e]) + bv;
+            for (int tt = 0; tt < TTW; ++tt) {
+                const int64_t tok = m0 + tt * 32 + r;
+                if (tok < T) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
                     if (EPI == 1) {
-                        v = gelu_erf_fast(v);
-                        _Float16 hi, lo;
-                        split_f16(v, hi, lo);
-                        oh_t[off] = hi;
-                        ol_t[off] = lo;
+                        half4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            _Float16 a, c;
+                            split_act(gelu_erf_fast(v[j]), a, c);
+                            hi[j] = a;
+                            lo[j] = c;
+                        }
+                        *reinterpret_cast<half4*>(oh + tok * N + feat) = hi;
+                        *reinterpret_cast<half4*>(ol + tok * N + feat) = lo;
                     } else {
-                        out_t[off] = v;
+                        *reinterpret_cast<f32x4*>(out + tok * N + feat) = v;
                     }
                 }
+            }
+        }
+}
+
+// Residual + LayerNorm epilogue of a [384-feature x (32 TTW)-token] block whose wave q holds features
+// q*96 .. q*96+95 (tf:292 / tf:350: LN(dense(.) + bias + x)).  The rows are parked in LDS 32 tokens at a time and
+// normalised by the same ln_row as add_ln_kernel (one wave per row, identical reduction order), so the fused
+// kernels and the unfused small-batch path give the same bits.  smem: >= 32 * 1552 B, free to overwrite.
+constexpr int LN_PARK_LD = 388;  // floats per parked row (+16 B: the 16-B writes of 8 tokens hit distinct banks)
+constexpr int LN_PARK_BYTES = 32 * LN_PARK_LD * 4;
+template <int TTW>
+__device__ __forceinline__ void wt_ln_epilogue(const f32x16 (&acc)[3][TTW], const float* __restrict__ bias,
+                                               float* __restrict__ x, _Float16* __restrict__ xh,
+                                               _Float16* __restrict__ xl, int64_t m0, int64_t T,
+                                               const float* __restrict__ gam, const float* __restrict__ bet, float eps,
+                                               char* smem) {
+    float* As = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tt = 0; tt < TTW; ++tt) {
+        __syncthreads();  // the k-loop's (or the previous pass's) readers of this LDS are done
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
+                *reinterpret_cast<f32x4*>(As + r * LN_PARK_LD + feat) = v;
+            }
+        __syncthreads();
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = q * 8 + rr;
+            const int64_t tok = m0 + tt * 32 + row;
+            if (tok < T) {  // wave-uniform
+                float v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[j] = As[row * LN_PARK_LD + lane + 64 * j] + x[tok * 384 + lane + 64 * j];
+                ln_row<384, true>(v, gam, bet, eps, x + tok * 384, xh + tok * 384, xl + tok * 384, lane);
             }
         }
     }
 }
 
-// W (fp32) -> f16 hi/lo planes, once at encoder creation.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, size_t n,
-                                                           _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        _Float16 a, b;
-        split_f16(w[i], a, b);
-        hi[i] = a;
-        lo[i] = b;
+// Attention-output projection + residual + LayerNorm in one kernel (large batches): block = 64 tokens x all 384
+// features, K = 384.
+template <int D>
+__global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __restrict__ Ah,
+                                                              const _Float16* __restrict__ Al, int T, int K,
+                                                              const _Float16* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ x,
+                                                              _Float16* __restrict__ xh, _Float16* __restrict__ xl,
+                                                              const float* __restrict__ gam,
+                                                              const float* __restrict__ bet, float eps) {
+    constexpr int SM = XRing<2>::BYTES > LN_PARK_BYTES ? XRing<2>::BYTES : LN_PARK_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM];
+    const int q = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    f32x16 acc[3][2];
+    wt_kloop<3, 2, D>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);
+    wt_ln_epilogue<2>(acc, bias, x, xh, xl, m0, T, gam, bet, eps, smem);
+}
+
+// ---------------------------------------------------------------- fused FFN (large batches)
+// x <- LN(W2 . gelu(W1 . x + b1) + b2 + x)   (tf:334-351: BertIntermediate, BertOutput) for a block of 64 tokens,
+// without the [T, 1536] intermediate ever leaving the CU.  The 1,536 intermediate features are walked in 12 chunks
+// of 128; per chunk
+//   P1  S^T[128 x 64 tok] = W1[chunk] . X^T          K = 384; wave q: intermediates q*32..+31 (2 token tiles)
+//   G   H = split(gelu(S * 2^-14 + b1))              registers -> 8-byte LDS writes (4 consecutive k of a token)
+//   P2  Y^T[384 x 64 tok] += W2[:, chunk] . H^T      K = 128; wave q: features q*96..+95 (3 x 2 tiles, 96 regs)
+// then the residual + LayerNorm epilogue.  Per output the MFMA chain is exactly wt_kloop's (k-steps ascending,
+// the same three products per step), so the result equals FFN-up -> FFN-down -> add_ln through wt_linear_kernel
+// bit for bit.  Weight fragments go global -> registers (W1: 4 k-steps ahead, W2: 2 k-steps ahead); the token
+// slab ring is the only shared operand.  LDS: 32 KB slab ring + 32 KB H = 64 KB -> two workgroups per CU, whose
+// phases drift apart so that one's GELU (VALU) overlaps the other's MFMAs.
+constexpr int FFN_IC = 128;
+template <int UNUSED>
+__global__ __launch_bounds__(256, 2) void ffn_fused_kernel(float* __restrict__ x, _Float16* __restrict__ xh,
+                                                           _Float16* __restrict__ xl, int T, int I,
+                                                           const _Float16* __restrict__ W1p,
+                                                           const float* __restrict__ b1,
+                                                           const _Float16* __restrict__ W2p,
+                                                           const float* __restrict__ b2,
+                                                           const float* __restrict__ gam,
+                                                           const float* __restrict__ bet, float eps) {
+    constexpr int K1 = 384, KS1 = K1 / 16, NSLAB = K1 / 64;
+    constexpr int HS_PLANE = 64 * 256;  // H: 64 tokens x 128 k halfs per plane (256-B rows, chunk ^ (token & 15))
+    __shared__ __attribute__((aligned(16))) char smem[XRing<2>::BYTES + 2 * HS_PLANE];
+    static_assert(XRing<2>::BYTES + 2 * HS_PLANE >= LN_PARK_BYTES, "LN parking area");
+    char* const Hs = smem + XRing<2>::BYTES;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int NC = I / FFN_IC, KS2 = I / 16;
+    const _Float16* const w1l = W1p + lane * 8;
+    const _Float16* w2p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2) + lane * 8;
+
+    f32x16 Y[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Y[i][tt][e] = 0.0f;
+
+    half8 w1h[4][1], w1lo[4][1];
+    half8 w2h[2][3], w2lo[2][3];
+    u32x4 xr[4];
+    x_load<2>(xr, xh, xl, m0, T, K1, 0);
+    {
+        const _Float16* const wp1[1] = {w1l + wt_frag_off(q, 0, KS1)};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w_load<1>(w1h[d], w1lo[d], wp1, d);
+    }
+    x_store<2>(xr, smem);
+    x_load<2>(xr, xh, xl, m0, T, K1, 1);
+    __syncthreads();
+
+    for (int c = 0; c < NC; ++c) {
+        const _Float16* const wp1[1] = {w1l + wt_frag_off(c * 4 + q, 0, KS1)};
+        // ---- P1
+        f32x16 S[1][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+            const char* st = smem + (s & 1) * XRing<2>::STAGE_BYTES;  // NSLAB is even: stage parity = s & 1 in every chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half8 fh[2], fl[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    fh[tt] = x_frag(st, tt, j, r, h);
+                    fl[tt] = x_frag(st + XRing<2>::PLANE_BYTES, tt, j, r, h);
+                }
+                wt_mma<1, 2>(S, w1h[j], w1lo[j], fh, fl);
+                if (4 * s + j + 4 < KS1) w_load<1>(w1h[j], w1lo[j], wp1, 4 * s + j + 4);
+            }
+            // next slab (wraps to slab 0 of the same token rows for the next chunk)
+            const bool more = (s + 1 < NSLAB) || (c + 1 < NC);
+            if (more) {
+                x_store<2>(xr, smem + ((s + 1) & 1) * XRing<2>::STAGE_BYTES);
+                // the load of the slab after next: slab 1 of the next chunk is issued late in P2 instead (its
+                // 16 registers are then free during the GELU)
+                if (s + 2 < NSLAB || (s + 2 == NSLAB && c + 1 < NC)) x_load<2>(xr, xh, xl, m0, T, K1, (s + 2) % NSLAB);
+            }
+            __syncthreads();
+        }
+        // ---- the first W2 fragments of this chunk fly during the GELU
+        w_load<3>(w2h[0], w2lo[0], w2p, c * 8);
+        // ---- G: bias + erf-GELU + split, 4 consecutive k of one token per 8-byte LDS write
+        {
+            const float* bp = b1 + c * FFN_IC + q * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    half4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 a, d;
+                        split_act(gelu_erf_fast(fmaf(S[0][tt][4 * g + j], WT_UNSCALE, b[j])), a, d);
+                        hi[j] = a;
+                        lo[j] = d;
+                    }
+                    const int tok = tt * 32 + r;
+                    const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
+                    *reinterpret_cast<half4*>(Hs + pos) = hi;
+                    *reinterpret_cast<half4*>(Hs + HS_PLANE + pos) = lo;
+                }
+            }
+        }
+        w_load<3>(w2h[1], w2lo[1], w2p, c * 8 + 1);
+        __syncthreads();
+        // ---- P2
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            half8 fh[2], fl[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int tok = tt * 32 + r;
+                const int pos = tok * 256 + (((2 * k2 + h) ^ (tok & 15)) << 4);
+                fh[tt] = *reinterpret_cast<const half8*>(Hs + pos);
+                fl[tt] = *reinterpret_cast<const half8*>(Hs + HS_PLANE + pos);
+            }
+            wt_mma<3, 2>(Y, w2h[k2 & 1], w2lo[k2 & 1], fh, fl);
+            if (k2 + 2 < 8) w_load<3>(w2h[k2 & 1], w2lo[k2 & 1], w2p, c * 8 + k2 + 2);
+            if (k2 >= 4 && c + 1 < NC) {  // next chunk's first W1 fragments
+                const _Float16* const wn[1] = {w1l + wt_frag_off((c + 1) * 4 + q, 0, KS1)};
+                w_load<1>(w1h[k2 - 4], w1lo[k2 - 4], wn, k2 - 4);
+            }
+            if (k2 == 6 && c + 1 < NC) x_load<2>(xr, xh, xl, m0, T, K1, 1);
+        }
+    }
+    wt_ln_epilogue<2>(Y, b2, x, xh, xl, m0, T, gam, bet, eps, smem);
+}
+
+// W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int N, int K,
+                                                           _Float16* __restrict__ out) {
+    const int KS = K / 16;
+    const size_t n = (size_t)(N / 32) * KS * 64;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (size_t)gridDim.x * 256) {
+        const size_t fr = id >> 6;
+        const int lane = (int)(id & 63), r = lane & 31, h = lane >> 5;
+        const int nt = (int)(fr / KS), ks = (int)(fr % KS);
+        const float* src = w + (size_t)(nt * 32 + r) * K + ks * 16 + 8 * h;
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            split_scaled(src[j], WT_SW, a, b);
+            hi[j] = a;
+            lo[j] = b;
+        }
+        *reinterpret_cast<half8*>(out + fr * (2 * WT_FRAG) + lane * 8) = hi;
+        *reinterpret_cast<half8*>(out + fr * (2 * WT_FRAG) + WT_FRAG + lane * 8) = lo;
     }
 }
 
@@ -371,7 +583,7 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(const float* __re
             const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
             if (SPLIT) {
                 _Float16 hi, lo;
-                split_f16(v, hi, lo);
+                split_act(v, hi, lo);
                 ch[at] = hi;
                 cl[at] = lo;
             } else {
@@ -566,7 +778,7 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
             const int qrow = acc_row(e, lane);
             const float v = fmaf(o1[e], LO_UNSCALE, o0[e]) * __builtin_amdgcn_rcpf(Ls[wave * 32 + qrow]);
             _Float16 hi, lo;
-            split_f16(v, hi, lo);
+            split_act(v, hi, lo);
             ob[qrow * 32 + r] = hi;
             ob[32 * 32 + qrow * 32 + r] = lo;
         }
@@ -590,7 +802,7 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
                 const size_t at = (size_t)(t0 + tq) * H + hd * DH + r;
                 if (SPLIT) {
                     _Float16 hi, lo;
-                    split_f16(v, hi, lo);
+                    split_act(v, hi, lo);
                     ch[at] = hi;
                     cl[at] = lo;
                 } else {
@@ -647,15 +859,15 @@ constexpr int HID = 384;
 
 struct LayerW {
     float *Wqkv, *bqkv, *Wo, *bo, *g1, *b1n, *W1, *b1, *W2, *b2, *g2, *b2n;
-    // f16 hi/lo planes of the four weight matrices (gemm_mode F16X3 only)
-    _Float16 *Wqkv_h, *Wqkv_l, *Wo_h, *Wo_l, *W1_h, *W1_l, *W2_h, *W2_l;
+    // the four weight matrices as packed f16 hi/lo fragments (wt_gemm.h; gemm_mode F16X3 only)
+    _Float16 *Wqkv_p, *Wo_p, *W1_p, *W2_p;
 };
 struct Encoder {
     icrec_bert_cfg cfg;
     int device = 0;
     float* blob = nullptr;      // the uploaded weight blob
     float* extra = nullptr;     // repacked Wqkv / bqkv
-    _Float16* planes = nullptr; // split weight planes (F16X3)
+    _Float16* planes = nullptr; // packed weight fragments (F16X3)
     float *word, *pos, *type, *eg, *eb;
     LayerW layers[64];
 };
@@ -685,9 +897,7 @@ static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T) {
 }
 
 typedef TileCfg<2, 2, 2, 2> GemmBig;  // 128 x 128 output tile, 4 waves
-typedef TileCfg<2, 4, 2, 1> GemmX3;   // 128 x 128 output tile, 8 waves of 64 x 32 (two accumulator sets per tile)
-typedef TileCfg<2, 2, 1, 1> GemmX3Small;  // 64 x 64, 4 waves of one 32 x 32 tile: the small-M form (M <= X3_SMALL_M tokens)
-constexpr int X3_SMALL_M = 512, X3_SMALL_DEPTH = 2;
+constexpr int X3_SMALL_M = 512;  // <= this many tokens: the latency form (32-token x 128-feature blocks, many workgroups)
 
 template <bool GELU>
 static void launch_linear(const float* A, int M, int K, const float* W, int N, const float* bias, float* out,
@@ -697,28 +907,22 @@ static void launch_linear(const float* A, int M, int K, const float* W, int N, c
                        bias, out, nt);
 }
 
+// f16x3 linear layer through the weights-direct engine.  Single requests / micro-batches are latency-bound (a
+// handful of workgroups, each walking its K loop): they use 32-token x 128-feature blocks — one 32x32 tile per
+// wave, as many workgroups as the shape allows; batches use 64-token x 384-feature blocks (3 x 2 tiles per
+// wave).  Per-output arithmetic is the same chain in both, so a request encodes to the same bits either way.
 template <int EPI>
-static int launch_linear_x3(const _Float16* Ah, const _Float16* Al, int M, int K, const _Float16* Wh,
-                            const _Float16* Wl, int N, const float* bias, float* out, _Float16* oh, _Float16* ol,
-                            hipStream_t st) {
-    if (M <= X3_SMALL_M) {
-        // Single requests / micro-batches are latency-bound on each wave's MFMA chain and on the slab loop, not
-        // on bandwidth (measured, 99 tokens: 128x128/8 waves 22 us per GEMM, 128x64/4 waves 18 us at any
-        // prefetch depth 1-6, 64x64/4 waves of ONE 32x32 tile 12 us): use the smallest per-wave tile and many
-        // workgroups.  Per-output arithmetic is unchanged, so results are bit-identical to the batch kernel.
-        auto kern = linear_x3_kernel<GemmX3Small, EPI, X3_SMALL_DEPTH>;
-        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)SmemH<GemmX3Small>::BYTES)) return rc_;
-        const int mt = (M + GemmX3Small::BM - 1) / GemmX3Small::BM, nt = (N + GemmX3Small::BN - 1) / GemmX3Small::BN;
-        hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(GemmX3Small::THREADS), SmemH<GemmX3Small>::BYTES, st, Ah, Al, M, K,
-                           Wh, Wl, N, bias, out, oh, ol, nt);
-        return ICREC_OK;
+static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int K, const _Float16* Wp, int N,
+                             const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
+    if (T <= X3_SMALL_M) {
+        const int nbn = N / 128;
+        hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
+                           Wp, N, bias, out, oh, ol, nbn);
+    } else {
+        const int nbn = N / 384;
+        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, EPI>), dim3(((T + 63) / 64) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
+                           Wp, N, bias, out, oh, ol, nbn);
     }
-    auto kern = linear_x3_kernel<GemmX3, EPI>;
-    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)SmemH<GemmX3>::BYTES)) return rc_;
-    const int mt = (M + GemmX3::BM - 1) / GemmX3::BM, nt = (N + GemmX3::BN - 1) / GemmX3::BN;
-    hipLaunchKernelGGL(kern, dim3(mt * nt), dim3(GemmX3::THREADS), SmemH<GemmX3>::BYTES, st, Ah, Al, M, K, Wh, Wl, N,
-                       bias, out, oh, ol, nt);
-    return ICREC_OK;
 }
 
 // Launch every length bucket that can occur for max_seqlen (a bucket whose workgroups all exit
@@ -755,7 +959,7 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     ICREC_REQUIRE(weights_host && cfg && out, "icrec_encoder_create: NULL argument");
     ICREC_REQUIRE(cfg->hidden == HID, "icrec_encoder_create: this build supports hidden=384 only (got %d)", cfg->hidden);
     ICREC_REQUIRE(cfg->heads * DH == cfg->hidden, "icrec_encoder_create: head_dim must be 32 (heads=%d)", cfg->heads);
-    ICREC_REQUIRE(cfg->intermediate >= 128 && cfg->intermediate % HBK == 0, "icrec_encoder_create: bad intermediate size %d", cfg->intermediate);
+    ICREC_REQUIRE(cfg->intermediate >= 384 && cfg->intermediate % 384 == 0, "icrec_encoder_create: intermediate size must be a multiple of 384 (got %d)", cfg->intermediate);
     ICREC_REQUIRE(cfg->layers >= 1 && cfg->layers <= 64, "icrec_encoder_create: layers must be in [1,64]");
     ICREC_REQUIRE(cfg->vocab_size >= 1 && cfg->max_position >= 1 && cfg->type_vocab >= 1, "icrec_encoder_create: bad vocab/position sizes");
     ICREC_REQUIRE(cfg->n_normalize >= 0 && cfg->n_normalize <= 4, "icrec_encoder_create: n_normalize must be in [0,4]");
@@ -792,10 +996,10 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     e->eb = p;   p += H;
     float* x = e->extra;
     _Float16* pl = e->planes;
-    auto split = [&](const float* w, size_t n, _Float16*& hi, _Float16*& lo) {
-        hi = pl; pl += n;
-        lo = pl; pl += n;
-        hipLaunchKernelGGL(split_planes_kernel, dim3(1024), dim3(256), 0, 0, w, n, hi, lo);
+    auto pack = [&](const float* w, int N, int K, _Float16*& out) {  // [N, K] fp32 -> packed hi/lo fragments
+        out = pl;
+        pl += (size_t)2 * N * K;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(1024), dim3(256), 0, 0, w, N, K, out);
     };
     for (int l = 0; l < cfg->layers; ++l) {
         LayerW& L = e->layers[l];
@@ -811,10 +1015,10 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
         L.W2 = p; p += H * I; L.b2 = p; p += H;
         L.g2 = p; p += H; L.b2n = p; p += H;
         if (x3) {
-            split(L.Wqkv, 3 * H * H, L.Wqkv_h, L.Wqkv_l);
-            split(L.Wo, H * H, L.Wo_h, L.Wo_l);
-            split(L.W1, I * H, L.W1_h, L.W1_l);
-            split(L.W2, H * I, L.W2_h, L.W2_l);
+            pack(L.Wqkv, (int)(3 * H), (int)H, L.Wqkv_p);
+            pack(L.Wo, (int)H, (int)H, L.Wo_p);
+            pack(L.W1, (int)I, (int)H, L.W1_p);
+            pack(L.W2, (int)H, (int)I, L.W2_p);
         }
     }
     ICREC_HIP(hipGetLastError());
@@ -865,6 +1069,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const int H = c.hidden, I = c.intermediate;
     const int rows_grid = (T + 3) / 4;
     const bool x3 = c.gemm_mode == ICREC_GEMM_F16X3;
+    const char* fuse_env = getenv("ICREC_FUSE");  // ICREC_FUSE=0: A/B switch to the unfused kernels (read per call: tests flip it)
+    const bool fuse = !(fuse_env && fuse_env[0] == '0');
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -882,20 +1088,27 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& L = e->layers[l];
         if (x3) {
-            int rc = launch_linear_x3<0>(xh, xl, T, H, L.Wqkv_h, L.Wqkv_l, 3 * H, L.bqkv, qkv, nullptr, nullptr, st);
-            if (rc != ICREC_OK) return rc;
+            launch_wt_linear<0>(xh, xl, T, H, L.Wqkv_p, 3 * H, L.bqkv, qkv, nullptr, nullptr, st);
             launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
-            launch_linear_x3<0>(ch, cl, T, H, L.Wo_h, L.Wo_l, H, L.bo, t1, nullptr, nullptr, st);
-            hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
-                               c.ln_eps, xh, xl);
-            {
+            if (T > X3_SMALL_M && fuse) {
+                // attention-out + residual + LN, then the whole FFN block + residual + LN: two kernels per half layer
+                hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, st, ch, cl, T, H, L.Wo_p,
+                                   L.bo, x, xh, xl, L.g1, L.b1n, c.ln_eps);
                 ScopedTimer tm(T_FFN_UP, st);
-                rc = launch_linear_x3<1>(xh, xl, T, H, L.W1_h, L.W1_l, I, L.b1, nullptr, hh, hl, st);
+                hipLaunchKernelGGL((ffn_fused_kernel<0>), dim3((T + 63) / 64), dim3(256), 0, st, x, xh, xl, T, I, L.W1_p,
+                                   L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
+            } else {
+                launch_wt_linear<0>(ch, cl, T, H, L.Wo_p, H, L.bo, t1, nullptr, nullptr, st);
+                hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
+                                   c.ln_eps, xh, xl);
+                {
+                    ScopedTimer tm(T_FFN_UP, st);
+                    launch_wt_linear<1>(xh, xl, T, H, L.W1_p, I, L.b1, nullptr, hh, hl, st);
+                }
+                launch_wt_linear<0>(hh, hl, T, I, L.W2_p, H, L.b2, t1, nullptr, nullptr, st);
+                hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n,
+                                   c.ln_eps, xh, xl);
             }
-            if (rc != ICREC_OK) return rc;
-            launch_linear_x3<0>(hh, hl, T, I, L.W2_h, L.W2_l, H, L.b2, t1, nullptr, nullptr, st);
-            hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n,
-                               c.ln_eps, xh, xl);
         } else {
             launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
             launch_attention<false, false>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);

@@ -171,3 +171,25 @@ def test_two_stream_split_is_bitwise_identical(encoder):
     for _ in range(2):
         two = encoder.encode_packed(i_d, c_d, mx, cu_host=cu).cpu().numpy()
         np.testing.assert_array_equal(one, two)
+
+
+def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch):
+    """Batches above 512 tokens run attention-out + residual + LN and the whole FFN block (up, GELU, down,
+    residual, LN) as two fused kernels; ICREC_FUSE=0 runs the same arithmetic as separate GEMM / LayerNorm
+    launches.  Same per-output MFMA chains and the same ln_row => identical bits."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+
+    enc = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    ids, cu = syn.synthetic_token_batch(19, seed=5, mean_len=90, std_len=60, lo=3, hi=256)
+    assert int(cu[-1]) > 512
+    mx = int(np.diff(cu).max())
+    args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), mx)
+    fused = enc.encode_packed(*args).cpu().numpy()
+    monkeypatch.setenv("ICREC_FUSE", "0")
+    unfused = enc.encode_packed(*args).cpu().numpy()
+    monkeypatch.delenv("ICREC_FUSE")
+    np.testing.assert_array_equal(fused, unfused)
+    enc.close()
