@@ -9,6 +9,8 @@
 // and oracle/icrec_oracle.c reduction orders where a kernel says "oracle order".
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_x3.h"
 #include "wt_gemm.h"
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                                                            _Float16* __restrict__ oh, _Float16* __restrict__ ol,
                                                            int n_blocks_n) {
     __shared__ __attribute__((aligned(16))) char smem[XRing<TTW>::BYTES];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
     const int mt = blockIdx.x / n_blocks_n, nb = blockIdx.x % n_blocks_n;
     const int64_t m0 = (int64_t)mt * (32 * TTW);
     const int nt0 = (nb * 4 + q) * NTW;
@@ -233,7 +235,7 @@ __device__ __forceinline__ void wt_ln_epilogue(const f32x16 (&acc)[3][TTW], cons
                                                const float* __restrict__ gam, const float* __restrict__ bet, float eps,
                                                char* smem) {
     float* As = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int tt = 0; tt < TTW; ++tt) {
         __syncthreads();  // the k-loop's (or the previous pass's) readers of this LDS are done
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __
                                                               const float* __restrict__ bet, float eps) {
     constexpr int SM = XRing<2>::BYTES > LN_PARK_BYTES ? XRing<2>::BYTES : LN_PARK_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM];
-    const int q = threadIdx.x >> 6;
+    const int q = wave_uniform(threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     f32x16 acc[3][2];
     wt_kloop<3, 2, D>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);
@@ -290,133 +292,257 @@ __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __
 //   P2  Y^T[384 x 64 tok] += W2[:, chunk] . H^T      K = 128; wave q: features q*96..+95 (3 x 2 tiles, 96 regs)
 // then the residual + LayerNorm epilogue.  Per output the MFMA chain is exactly wt_kloop's (k-steps ascending,
 // the same three products per step), so the result equals FFN-up -> FFN-down -> add_ln through wt_linear_kernel
-// bit for bit.  Weight fragments go global -> registers (W1: 4 k-steps ahead, W2: 2 k-steps ahead); the token
-// slab ring is the only shared operand.  LDS: 32 KB slab ring + 32 KB H = 64 KB -> two workgroups per CU, whose
-// phases drift apart so that one's GELU (VALU) overlaps the other's MFMAs.
+// bit for bit.
 constexpr int FFN_IC = 128;
-template <int UNUSED>
-__global__ __launch_bounds__(256, 2) void ffn_fused_kernel(float* __restrict__ x, _Float16* __restrict__ xh,
-                                                           _Float16* __restrict__ xl, int T, int I,
-                                                           const _Float16* __restrict__ W1p,
-                                                           const float* __restrict__ b1,
-                                                           const _Float16* __restrict__ W2p,
-                                                           const float* __restrict__ b2,
-                                                           const float* __restrict__ gam,
-                                                           const float* __restrict__ bet, float eps) {
-    constexpr int K1 = 384, KS1 = K1 / 16, NSLAB = K1 / 64;
-    constexpr int HS_PLANE = 64 * 256;  // H: 64 tokens x 128 k halfs per plane (256-B rows, chunk ^ (token & 15))
-    __shared__ __attribute__((aligned(16))) char smem[XRing<2>::BYTES + 2 * HS_PLANE];
-    static_assert(XRing<2>::BYTES + 2 * HS_PLANE >= LN_PARK_BYTES, "LN parking area");
-    char* const Hs = smem + XRing<2>::BYTES;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+
+// Producer / consumer form: one 8-wave workgroup per CU owning ALL 160 KB of LDS:
+//   * the block's 64 x 384 activation planes stay resident in LDS (96 KB) for all 12 chunks — no restream, no
+//     slab barriers;
+//   * waves 0-3 (producers) run P1 + GELU for chunk c+1 and write H into one half of a double buffer (2 x 32 KB)
+//     while waves 4-7 (consumers) run P2 of chunk c from the other half: ONE workgroup barrier per chunk;
+//   * each SIMD hosts one producer and one consumer.  They issue the same number of MFMAs per chunk (144 each);
+//     the producer runs at raised priority, so it finishes P1 early and its GELU (VALU) overlaps the consumer's
+//     MFMAs;
+//   * specialisation frees registers for deep weight prefetch rings (W1: 8 k-steps, W2: 4 k-steps ahead).
+constexpr int FFN2_XPLANE = 64 * 768;                    // [64 tokens][384 k] halfs: 768-B rows, 3 sub-rows of 256 B
+constexpr int FFN2_X_BYTES = 2 * FFN2_XPLANE;            // hi, lo
+constexpr int FFN2_HPLANE = 64 * 256;                    // [64 tokens][128 k] halfs
+constexpr int FFN2_HBUF = 2 * FFN2_HPLANE;               // hi, lo
+constexpr int FFN2_LDS = FFN2_X_BYTES + 2 * FFN2_HBUF;   // 163,840 B = the whole LDS of a CU
+static_assert(FFN2_LDS == 160 * 1024, "fused FFN LDS budget");
+static_assert(64 * LN_PARK_LD * 4 <= FFN2_LDS, "LN parking area");
+
+__device__ __forceinline__ void bar_lds() {  // LDS hand-off barrier that leaves global loads in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ x, _Float16* __restrict__ xh,
+                                                            _Float16* __restrict__ xl, int T, int I,
+                                                            const _Float16* __restrict__ W1p,
+                                                            const float* __restrict__ b1,
+                                                            const _Float16* __restrict__ W2p,
+                                                            const float* __restrict__ b2,
+                                                            const float* __restrict__ gam,
+                                                            const float* __restrict__ bet, float eps) {
+    constexpr int KS1 = 24;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    char* const Xs = smem2;
+    char* const Hs = smem2 + FFN2_X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), q = wave & 3, r = lane & 31, h = lane >> 5;
+    const bool producer = wave < 4;
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     const int NC = I / FFN_IC, KS2 = I / 16;
-    const _Float16* const w1l = W1p + lane * 8;
-    const _Float16* w2p[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2) + lane * 8;
 
-    f32x16 Y[3][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Y[i][tt][e] = 0.0f;
-
-    half8 w1h[4][1], w1lo[4][1];
-    half8 w2h[2][3], w2lo[2][3];
-    u32x4 xr[4];
-    x_load<2>(xr, xh, xl, m0, T, K1, 0);
+    // ---- the block's activation planes -> LDS, once (16-B chunk c of token row t at sub-row c >> 4, slot (c ^ t) & 15)
     {
-        const _Float16* const wp1[1] = {w1l + wt_frag_off(q, 0, KS1)};
+        u32x4 vh[6], vl[6];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) w_load<1>(w1h[d], w1lo[d], wp1, d);
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            int64_t g = m0 + row;
+            g = g < T ? g : (int64_t)T - 1;
+            vh[i] = *reinterpret_cast<const u32x4*>(xh + g * 384 + c * 8);
+            vl[i] = *reinterpret_cast<const u32x4*>(xl + g * 384 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
+            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
+            *reinterpret_cast<u32x4*>(Xs + FFN2_XPLANE + pos) = vl[i];
+        }
     }
-    x_store<2>(xr, smem);
-    x_load<2>(xr, xh, xl, m0, T, K1, 1);
-    __syncthreads();
 
-    for (int c = 0; c < NC; ++c) {
-        const _Float16* const wp1[1] = {w1l + wt_frag_off(c * 4 + q, 0, KS1)};
-        // ---- P1
-        f32x16 S[1][2];
+    const unsigned lo8 = lane * 8;
+    f32x16 Y[3][2];  // consumers only (dead in the producer branch)
+    if (producer) {
+        // LDS byte address of this lane's fragment of token tile tt at 16-B chunk ch = 2 ks + h:
+        //   tok*768 + (ch >> 4)*256 + (((ch & 15) ^ (tok & 15)) << 4),  (ch & 15) ^ t = 2 (ks & 7) ^ (h ^ t)
+        int xb[8][2];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int tok = tt * 32 + r;
+                xb[m][tt] = tok * 768 + (((2 * m) ^ h ^ (tok & 15)) << 4);
+            }
+        half8 wh[8][1], wl[8][1];
+        {
+            const _Float16* const wp0[1] = {W1p + wt_frag_off(q, 0, KS1)};
+#pragma unroll
+            for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
+        }
+        __syncthreads();  // X resident
+        // Software pipeline: iteration c runs P1(c) with the GELU of chunk c-1 spread over its k-steps (one group
+        // of 4 intermediates x 1 token tile every third k-step), so the producer's VALU work sits between its own
+        // MFMAs and the consumers' instead of behind them.  H[c-1] is handed over at the end of iteration c.
+        f32x16 S[1][2], Sp[1][2];  // this chunk's accumulators, the previous chunk's (being GELU'd)
+        f32x4 bias[4], biasp[4];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) Sp[0][tt][e] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {
-            const char* st = smem + (s & 1) * XRing<2>::STAGE_BYTES;  // NSLAB is even: stage parity = s & 1 in every chunk
+        for (int g = 0; g < 4; ++g) biasp[g] = bias[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // one pipeline iteration: P1(c) (MMA = true) with G(c - 1) spread over its 24 k-steps; the drain iteration
+        // (MMA = false) runs only the G slices
+        auto iteration = [&](int c, auto mma_tag) {
+            constexpr bool MMA = decltype(mma_tag)::value;
+            const _Float16* const wp1[1] = {W1p + wt_frag_off((MMA ? c : 0) * 4 + q, 0, KS1)};
+            const _Float16* const wpn[1] = {W1p + wt_frag_off((MMA && c + 1 < NC ? c + 1 : 0) * 4 + q, 0, KS1)};
+            if (MMA) {  // this chunk's biases, loaded BEFORE the k-loop: a load issued behind the weight ring would make
+                        // its consumer wait for the whole ring (vmcnt counts in order)
+                const float* bp = b1 + c * FFN_IC + q * 32 + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half8 fh[2], fl[2];
+                for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+            char* const Hb = Hs + ((c + 1) & 1) * FFN2_HBUF;  // H[(c - 1) & 1]
+            half8 fh[2][2], fl[2][2];  // the next k-step's fragments are read under the current one's MFMAs
+            if (MMA) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    fh[tt] = x_frag(st, tt, j, r, h);
-                    fl[tt] = x_frag(st + XRing<2>::PLANE_BYTES, tt, j, r, h);
+                    fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb[0][tt]);
+                    fl[0][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + xb[0][tt]);
                 }
-                wt_mma<1, 2>(S, w1h[j], w1lo[j], fh, fl);
-                if (4 * s + j + 4 < KS1) w_load<1>(w1h[j], w1lo[j], wp1, 4 * s + j + 4);
             }
-            // next slab (wraps to slab 0 of the same token rows for the next chunk)
-            const bool more = (s + 1 < NSLAB) || (c + 1 < NC);
-            if (more) {
-                x_store<2>(xr, smem + ((s + 1) & 1) * XRing<2>::STAGE_BYTES);
-                // the load of the slab after next: slab 1 of the next chunk is issued late in P2 instead (its
-                // 16 registers are then free during the GELU)
-                if (s + 2 < NSLAB || (s + 2 == NSLAB && c + 1 < NC)) x_load<2>(xr, xh, xl, m0, T, K1, (s + 2) % NSLAB);
-            }
-            __syncthreads();
-        }
-        // ---- the first W2 fragments of this chunk fly during the GELU
-        w_load<3>(w2h[0], w2lo[0], w2p, c * 8);
-        // ---- G: bias + erf-GELU + split, 4 consecutive k of one token per 8-byte LDS write
-        {
-            const float* bp = b1 + c * FFN_IC + q * 32 + 4 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+            for (int ks = 0; ks < KS1; ++ks) {
+                if (MMA) {
+                    if (ks + 1 < KS1 && !(VAR & 8)) {
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const int pos = xb[(ks + 1) & 7][tt] + ((ks + 1) >> 3) * 256;
+                            fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
+                            fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
+                        }
+                    }
+                    wt_mma<1, 2>(S, wh[ks & 7], wl[ks & 7], fh[(VAR & 8) ? 0 : (ks & 1)], fl[(VAR & 8) ? 0 : (ks & 1)]);
+                    if (!(VAR & 4)) {  // straight-line refill: this chunk's k-step ks+8, or the next chunk's ks+8-24
+                        if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
+                        else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
+                    }
+                }
+                if (ks % 3 == 0) {  // G group ks/3 of the PREVIOUS chunk: bias + erf-GELU + split, one 8-byte LDS write per plane
+                    const int gi = ks / 3, g = gi >> 1, tt = gi & 1;
                     half4 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         _Float16 a, d;
-                        split_act(gelu_erf_fast(fmaf(S[0][tt][4 * g + j], WT_UNSCALE, b[j])), a, d);
+                        const float pre = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
+                        split_act((VAR & 1) ? pre : gelu_erf_fast(pre), a, d);
                         hi[j] = a;
                         lo[j] = d;
                     }
                     const int tok = tt * 32 + r;
                     const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
-                    *reinterpret_cast<half4*>(Hs + pos) = hi;
-                    *reinterpret_cast<half4*>(Hs + HS_PLANE + pos) = lo;
+                    *reinterpret_cast<half4*>(Hb + pos) = hi;  // iteration 0 writes GELU(0) into a buffer nobody reads yet
+                    *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = lo;
                 }
+                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch (and the GELU slice) to its k-step
             }
-        }
-        w_load<3>(w2h[1], w2lo[1], w2p, c * 8 + 1);
-        __syncthreads();
-        // ---- P2
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            half8 fh[2], fl[2];
+            for (int tt = 0; tt < 2; ++tt) Sp[0][tt] = S[0][tt];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) biasp[g] = bias[g];
+        };
+        for (int c = 0; c < NC; ++c) {
+            iteration(c, std::true_type{});
+            if (c > 0) bar_lds();  // B(c): H[c - 1] is complete; the consumers have left H[c & 1]
+        }
+        iteration(NC, std::false_type{});
+        bar_lds();  // B(NC): H[NC - 1]
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Y[i][tt][e] = 0.0f;
+        const _Float16* w2p[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2);
+        int hb[2];  // tok*256 + ((h ^ (tok & 15)) << 4); chunk 2 k2 + h lands at hb ^ (k2 << 5)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) hb[tt] = (tt * 32 + r) * 256 + ((h ^ (r & 15)) << 4);
+        half8 wh[4][3], wl[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
+        __syncthreads();  // X resident (matches the producers' first barrier)
+        bar_lds();        // B1: H[0] is ready
+        for (int c = 0; c < NC; ++c) {
+            const char* const Hb = Hs + (c & 1) * FFN2_HBUF;
+            half8 fh[2][2], fl[2][2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int tok = tt * 32 + r;
-                const int pos = tok * 256 + (((2 * k2 + h) ^ (tok & 15)) << 4);
-                fh[tt] = *reinterpret_cast<const half8*>(Hs + pos);
-                fl[tt] = *reinterpret_cast<const half8*>(Hs + HS_PLANE + pos);
+                fh[0][tt] = *reinterpret_cast<const half8*>(Hb + hb[tt]);
+                fl[0][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + hb[tt]);
             }
-            wt_mma<3, 2>(Y, w2h[k2 & 1], w2lo[k2 & 1], fh, fl);
-            if (k2 + 2 < 8) w_load<3>(w2h[k2 & 1], w2lo[k2 & 1], w2p, c * 8 + k2 + 2);
-            if (k2 >= 4 && c + 1 < NC) {  // next chunk's first W1 fragments
-                const _Float16* const wn[1] = {w1l + wt_frag_off((c + 1) * 4 + q, 0, KS1)};
-                w_load<1>(w1h[k2 - 4], w1lo[k2 - 4], wn, k2 - 4);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                if (k2 + 1 < 8 && !(VAR & 8)) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int pos = hb[tt] ^ ((k2 + 1) << 5);
+                        fh[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + pos);
+                        fl[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + pos);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // issue the next step's LDS reads before this step's 18 MFMAs
+                }
+                wt_mma<3, 2>(Y, wh[k2 & 3], wl[k2 & 3], fh[(VAR & 8) ? 0 : (k2 & 1)], fl[(VAR & 8) ? 0 : (k2 & 1)]);
+                if (!(VAR & 4)) {
+                    int nk = c * 8 + k2 + 4;
+                    nk = nk < KS2 ? nk : KS2 - 1;  // past the end: re-read the last fragment (never consumed)
+                    w_load<3>(wh[k2 & 3], wl[k2 & 3], w2p, nk, lo8);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
             }
-            if (k2 == 6 && c + 1 < NC) x_load<2>(xr, xh, xl, m0, T, K1, 1);
+            if (c + 1 < NC) bar_lds();  // B(c+2): done with H[c & 1]; H[(c + 1) & 1] is ready
         }
     }
-    wt_ln_epilogue<2>(Y, b2, x, xh, xl, m0, T, gam, bet, eps, smem);
+    // ---- residual + LayerNorm: consumers park all 64 rows (the X / H areas are free now), every wave normalises 8
+    // rows whose residual values were requested before the hand-off barrier
+    float* As = reinterpret_cast<float*>(smem2);
+    float xres[8][6];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        int64_t tok = m0 + wave * 8 + rr;
+        tok = tok < T ? tok : (int64_t)T - 1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xres[rr][j] = x[tok * 384 + lane + 64 * j];
+    }
+    __syncthreads();
+    if (!producer) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + feat);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(Y[i][tt][4 * g + j], WT_UNSCALE, b[j]);
+                    *reinterpret_cast<f32x4*>(As + (tt * 32 + r) * LN_PARK_LD + feat) = v;
+                }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = wave * 8 + rr;
+        const int64_t tok = m0 + row;
+        if (tok < T) {  // wave-uniform
+            float v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = As[row * LN_PARK_LD + lane + 64 * j] + xres[rr][j];
+            ln_row<384, true>(v, gam, bet, eps, x + tok * 384, xh + tok * 384, xl + tok * 384, lane);
+        }
+    }
 }
 
 // W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.
@@ -1095,8 +1221,10 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, st, ch, cl, T, H, L.Wo_p,
                                    L.bo, x, xh, xl, L.g1, L.b1n, c.ln_eps);
                 ScopedTimer tm(T_FFN_UP, st);
-                hipLaunchKernelGGL((ffn_fused_kernel<0>), dim3((T + 63) / 64), dim3(256), 0, st, x, xh, xl, T, I, L.W1_p,
-                                   L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
+                auto kern = ffn_fused2_kernel<0>;
+                if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
+                hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, st, x, xh, xl, T, I, L.W1_p, L.b1,
+                                   L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
             } else {
                 launch_wt_linear<0>(ch, cl, T, H, L.Wo_p, H, L.bo, t1, nullptr, nullptr, st);
                 hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,

@@ -111,15 +111,20 @@ __device__ __forceinline__ void wt_mma(f32x16 (&acc)[NTW][TTW], const half8 (&wh
         }
 }
 
+// Weight fragments of k-step `ks` for NTW tiles.  `wp[i]` and `ks` are wave-uniform (scalar registers), `lo8` is the
+// lane's offset in halfs (lane * 8): the loads are global_load_dwordx4 with a scalar base, no per-load VALU.
 template <int NTW>
-__device__ __forceinline__ void w_load(half8 (&wh)[NTW], half8 (&wl)[NTW], const _Float16* const (&wp)[NTW], int ks) {
+__device__ __forceinline__ void w_load(half8 (&wh)[NTW], half8 (&wl)[NTW], const _Float16* const (&wp)[NTW], int ks,
+                                       unsigned lo8) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const _Float16* p = wp[i] + (size_t)ks * (2 * WT_FRAG);
-        wh[i] = *reinterpret_cast<const half8*>(p);
-        wl[i] = *reinterpret_cast<const half8*>(p + WT_FRAG);
+        wh[i] = *reinterpret_cast<const half8*>(p + lo8);
+        wl[i] = *reinterpret_cast<const half8*>(p + WT_FRAG + lo8);
     }
 }
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------- whole-K loop of one output tile
 // acc[i][tt] = sum_k W[(nt0 + i) tile][k] . X[m0 + tt tile][k], K in slabs of 64 (4 k-steps); weight fragments
@@ -131,10 +136,11 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
                                          int64_t T, char* smem) {
     static_assert(D == 1 || D == 2 || D == 4, "prefetch depth must divide the 4 k-steps of a slab");
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const unsigned lo8 = lane * 8;
     const int KS = K / 16, nslab = K / 64;
-    const _Float16* wp[NTW];
+    const _Float16* wp[NTW];  // wave-uniform (nt0 must be)
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) wp[i] = Wp + wt_frag_off(nt0 + i, 0, KS) + lane * 8;
+    for (int i = 0; i < NTW; ++i) wp[i] = Wp + wt_frag_off(nt0 + i, 0, KS);
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
@@ -145,25 +151,34 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
     u32x4 xr[2 * TTW];
     x_load<TTW>(xr, Xh, Xl, m0, T, K, 0);
 #pragma unroll
-    for (int d = 0; d < D; ++d) w_load<NTW>(wh[d], wl[d], wp, d);
+    for (int d = 0; d < D; ++d) w_load<NTW>(wh[d], wl[d], wp, d, lo8);
     x_store<TTW>(xr, smem);
     if (nslab > 1) x_load<TTW>(xr, Xh, Xl, m0, T, K, 1);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
         const char* st = smem + (s & 1) * XRing<TTW>::STAGE_BYTES;
+        half8 xh[2][TTW], xl[2][TTW];  // fragments of the next k-step are read under the current one's MFMAs
+#pragma unroll
+        for (int tt = 0; tt < TTW; ++tt) {
+            xh[0][tt] = x_frag(st, tt, 0, r, h);
+            xl[0][tt] = x_frag(st + XRing<TTW>::PLANE_BYTES, tt, 0, r, h);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            half8 xh[TTW], xl[TTW];
+            if (j < 3) {
 #pragma unroll
-            for (int tt = 0; tt < TTW; ++tt) {
-                xh[tt] = x_frag(st, tt, j, r, h);
-                xl[tt] = x_frag(st + XRing<TTW>::PLANE_BYTES, tt, j, r, h);
+                for (int tt = 0; tt < TTW; ++tt) {
+                    xh[(j + 1) & 1][tt] = x_frag(st, tt, j + 1, r, h);
+                    xl[(j + 1) & 1][tt] = x_frag(st + XRing<TTW>::PLANE_BYTES, tt, j + 1, r, h);
+                }
             }
-            wt_mma<NTW, TTW>(acc, wh[j % D], wl[j % D], xh, xl);
-            const int nk = 4 * s + j + D;
-            if (nk < KS) w_load<NTW>(wh[j % D], wl[j % D], wp, nk);
+            wt_mma<NTW, TTW>(acc, wh[j % D], wl[j % D], xh[j & 1], xl[j & 1]);
+            int nk = 4 * s + j + D;  // past the end: re-read the last fragment (never consumed) - no branch in the loop body
+            nk = nk < KS ? nk : KS - 1;
+            w_load<NTW>(wh[j % D], wl[j % D], wp, nk, lo8);
+            __builtin_amdgcn_sched_barrier(0);  // keep every prefetch in its k-step (the scheduler otherwise sinks the loads to their uses)
         }
-        if (s + 1 < nslab) {
+        if (s + 1 < nslab) {  // slab-granular (uniform) branches; the k-step body above is straight-line code
             x_store<TTW>(xr, smem + ((s + 1) & 1) * XRing<TTW>::STAGE_BYTES);
             if (s + 2 < nslab) x_load<TTW>(xr, Xh, Xl, m0, T, K, s + 2);
         }

@@ -1,0 +1,101 @@
+// Standalone timing harness for the weights-direct encoder kernels (fused FFN, QKV, attention-out + LN) on
+// random data at the bench shape, with the fused kernel's timing ablations (VAR bits, see encoder.hip).
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off tools/ffn_bench.hip \
+//        instacart_next_order_recommendation_amd/csrc/api.hip -o tools/_ffn_bench
+// Not part of the product; numbers from ablated variants are for attribution only.
+#include "../instacart_next_order_recommendation_amd/csrc/encoder.hip"
+
+#include <algorithm>
+#include <vector>
+
+using namespace icrec;
+
+__global__ void fill_half(_Float16* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        p[i] = (_Float16)(((float)(z & 0xFFFF) / 65536.0f - 0.5f) * scale);
+    }
+}
+__global__ void fill_float(float* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        p[i] = ((float)(z & 0xFFFF) / 65536.0f - 0.5f) * scale;
+    }
+}
+
+template <class F>
+static void timeit(const char* name, F&& launch, double flops) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i) launch();
+    hipDeviceSynchronize();
+    std::vector<float> ms;
+    for (int rep = 0; rep < 7; ++rep) {
+        hipEventRecord(a);
+        launch();
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float t; hipEventElapsedTime(&t, a, b);
+        ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    hipError_t e = hipGetLastError();
+    printf("%-46s min %8.1f us  median %8.1f us  %7.1f TF (algorithmic, median)%s\n", name, ms[0] * 1e3, ms[3] * 1e3,
+           flops / (ms[3] * 1e-3) / 1e12, e == hipSuccess ? "" : "  [HIP ERROR]");
+}
+
+int main(int argc, char** argv) {
+    const int T0 = argc > 1 ? atoi(argv[1]) : 131150;
+    const int H = 384, I = 1536;
+    float *x, *b1, *b2, *g, *bn, *qkv, *bq;
+    _Float16 *xh, *xl, *W1p, *W2p, *Wqp, *Wop, *ch, *cl;
+    const size_t Tmax = 140000;
+    hipMalloc(&x, Tmax * H * 4); hipMalloc(&xh, Tmax * H * 2); hipMalloc(&xl, Tmax * H * 2);
+    hipMalloc(&ch, Tmax * H * 2); hipMalloc(&cl, Tmax * H * 2);
+    hipMalloc(&qkv, Tmax * 3 * H * 4);
+    hipMalloc(&W1p, (size_t)2 * I * H * 2); hipMalloc(&W2p, (size_t)2 * I * H * 2);
+    hipMalloc(&Wqp, (size_t)2 * 3 * H * H * 2); hipMalloc(&Wop, (size_t)2 * H * H * 2);
+    hipMalloc(&b1, I * 4); hipMalloc(&b2, H * 4); hipMalloc(&g, H * 4); hipMalloc(&bn, H * 4); hipMalloc(&bq, 3 * H * 4);
+    auto reinit = [&]() {
+        fill_float<<<1024, 256>>>(x, Tmax * H, 1, 2.0f);
+        fill_half<<<1024, 256>>>(xh, Tmax * H, 2, 32.0f);   // ~ 16 * activation
+        fill_half<<<1024, 256>>>(xl, Tmax * H, 3, 0.02f);
+        fill_half<<<1024, 256>>>(ch, Tmax * H, 12, 32.0f);
+        fill_half<<<1024, 256>>>(cl, Tmax * H, 13, 0.02f);
+    };
+    reinit();
+    fill_half<<<1024, 256>>>(W1p, (size_t)2 * I * H, 4, 100.0f);  // ~ 1024 * weight
+    fill_half<<<1024, 256>>>(W2p, (size_t)2 * I * H, 5, 100.0f);
+    fill_half<<<1024, 256>>>(Wqp, (size_t)2 * 3 * H * H, 6, 100.0f);
+    fill_half<<<1024, 256>>>(Wop, (size_t)2 * H * H, 7, 100.0f);
+    fill_float<<<8, 256>>>(b1, I, 8, 0.04f); fill_float<<<8, 256>>>(b2, H, 9, 0.04f); fill_float<<<8, 256>>>(bq, 3 * H, 10, 0.04f);
+    fill_float<<<8, 256>>>(g, H, 11, 0.1f); fill_float<<<8, 256>>>(bn, H, 12, 0.04f);
+    hipDeviceSynchronize();
+
+    for (int T : {T0, 131072, 16384}) {
+        const double ffn_flops = 4.0 * T * H * I;
+        printf("---- T = %d tokens (%d blocks of 64)\n", T, (T + 63) / 64);
+#define FFN2(V)                                                                                                         \
+    timeit("ffn_fused2 (producer/consumer) VAR=" #V, [&] {                                                               \
+        auto kern = ffn_fused2_kernel<V>;                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);  \
+        hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, x, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); \
+    }, ffn_flops)
+        FFN2(0);
+        if (T == T0 || T == 131072) {
+            FFN2(1); FFN2(4); FFN2(5); FFN2(13); FFN2(16);
+        }
+        reinit();
+        timeit("qkv wt_linear<3,2,2,0> N=1152", [&] {
+            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
+        }, 2.0 * T * H * 3 * H);
+        timeit("attn-out + LN wt_linear_ln<2>", [&] {
+            hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
+        }, 2.0 * T * H * H);
+        reinit();
+        hipDeviceSynchronize();
+    }
+    return 0;
+}
