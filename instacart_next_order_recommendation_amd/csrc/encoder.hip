@@ -170,6 +170,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
     }
 }
 
+constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 16-B accesses of consecutive tokens hit distinct banks)
+
 // ---------------------------------------------------------------- f16x3 linear layers (wt_gemm.h)
 // out^T = W . X^T with the weights streamed straight from L2 into registers (packed fragment order) and the
 // token slab staged through LDS.  Block = 4 waves; wave q owns NTW 32-feature tiles x TTW 32-token tiles.
@@ -183,13 +185,48 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            _Float16* __restrict__ oh, _Float16* __restrict__ ol,
                                                            int n_blocks_n) {
-    __shared__ __attribute__((aligned(16))) char smem[XRing<TTW>::BYTES];
+    constexpr bool STAGED = (NTW == 3 && TTW == 2 && EPI == 0);  // batch form: results leave through an LDS stage, coalesced
+    constexpr int SM = (STAGED && 32 * LN_LD * 4 > XRing<TTW>::BYTES) ? 32 * LN_LD * 4 : XRing<TTW>::BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM];
     const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
     const int mt = blockIdx.x / n_blocks_n, nb = blockIdx.x % n_blocks_n;
     const int64_t m0 = (int64_t)mt * (32 * TTW);
     const int nt0 = (nb * 4 + q) * NTW;
     f32x16 acc[NTW][TTW];
     wt_kloop<NTW, TTW, D>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);
+    if constexpr (STAGED) {
+        // [384 features x 32 tokens] per pass -> stage[token][feature] (16-B LDS writes), then 16-B chunks in flat
+        // order: every wave store instruction writes 1 KB of at most two output rows.  (Storing 16 B per lane with
+        // the lanes 4,608 B apart took as long as the whole K loop: 32k of 69k cycles per block by in-kernel stamps.)
+        float* const stage = reinterpret_cast<float*>(smem);
+        const int n0 = nb * 384;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int fl = q * 96 + i * 32 + 8 * g + 4 * h;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n0 + fl);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
+                    *reinterpret_cast<f32x4*>(stage + r * LN_LD + fl) = v;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int f = threadIdx.x + 256 * k, row = f / 96, c = f - row * 96;
+                const int64_t tok = m0 + tt * 32 + row;
+                if (tok < T)
+                    *reinterpret_cast<f32x4*>(out + tok * N + n0 + c * 4) = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
+            }
+            if (tt == 0) __syncthreads();
+        }
+        ICREC_STAMP(0, 30);
+        return;
+    }
+
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
@@ -220,48 +257,223 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                 }
             }
         }
+    ICREC_STAMP(0, 30);
 }
 
-// Residual + LayerNorm epilogue of a [384-feature x (32 TTW)-token] block whose wave q holds features
-// q*96 .. q*96+95 (tf:292 / tf:350: LN(dense(.) + bias + x)).  The rows are parked in LDS 32 tokens at a time and
-// normalised by the same ln_row as add_ln_kernel (one wave per row, identical reduction order), so the fused
-// kernels and the unfused small-batch path give the same bits.  smem: >= 32 * 1552 B, free to overwrite.
-constexpr int LN_PARK_LD = 388;  // floats per parked row (+16 B: the 16-B writes of 8 tokens hit distinct banks)
-constexpr int LN_PARK_BYTES = 32 * LN_PARK_LD * 4;
-template <int TTW>
-__device__ __forceinline__ void wt_ln_epilogue(const f32x16 (&acc)[3][TTW], const float* __restrict__ bias,
-                                               float* __restrict__ x, _Float16* __restrict__ xh,
-                                               _Float16* __restrict__ xl, int64_t m0, int64_t T,
-                                               const float* __restrict__ gam, const float* __restrict__ bet, float eps,
-                                               char* smem) {
-    float* As = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+// Residual + LayerNorm (tf:292 / tf:350: LN(dense(.) + bias + x)) on the accumulators of a [384-feature x 64-token]
+// block.  Wave q (0..3 of the waves holding accumulators) owns features q*96 .. q*96+95: lane (r, h) holds, for token
+// tile tt, the 48 values of token tt*32 + r at features q*96 + i*32 + 8g + 4h + j (i < 3, g < 4, j < 4).
+//
+// The engine's LayerNorm reduction order (here and in add_ln_wt_kernel for the unfused path — same bits):
+//   part(q, h) = sum over (i, g, j), i outermost, of v            sequential fp32 adds from 0
+//   sum        = ((P0 + P1) + P2) + P3,   Pq = part(q, 0) + part(q, 1)
+//   mean = sum / 384;   d = v - mean;   the same tree over fmaf(d, d, .) chains;   var = that / 384
+//   y = fmaf(d * (1 / sqrtf(var + eps)), gamma, beta)
+// The statistics never leave the lanes (plus one 4-float exchange between the waves).  Global memory is touched
+// only by FLAT, fully coalesced passes: the residual rows come in and the normalised rows go out through an LDS
+// stage [rows][388 floats] — a lane-per-token 16-byte global access pattern costs 4x the whole K loop (measured with
+// in-kernel stamps: 73k cycles per block).  PT = token tiles per pass (stage = PT * 49,664 B, + 2 KB of reduction
+// scratch), NT = threads of the workgroup, `sync` its barrier; every thread must call, `active` = this wave holds
+// accumulators.
+template <int PT>
+struct LnStage {
+    static constexpr int STAGE_BYTES = PT * 32 * LN_LD * 4;
+    static constexpr int BYTES = STAGE_BYTES + 2 * PT * 32 * 4 * 4;
+};
+template <int PT, int NT, class Sync>
+__device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, int q, const float* __restrict__ bias,
+                                             float* __restrict__ x, _Float16* __restrict__ xh,
+                                             _Float16* __restrict__ xl, int64_t m0, int64_t T,
+                                             const float* __restrict__ gam, const float* __restrict__ bet, float eps,
+                                             char* lds, Sync sync) {
+    static_assert(PT == 1 || PT == 2, "token tiles per pass");
+    constexpr int ROWS = PT * 32, CHUNKS = ROWS * 96, PER = CHUNKS / NT;
+    static_assert(CHUNKS % NT == 0, "flat passes must divide evenly");
+    float* const stage = reinterpret_cast<float*>(lds);
+    float* const red = stage + ROWS * LN_LD;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int tt = 0; tt < TTW; ++tt) {
-        __syncthreads();  // the k-loop's (or the previous pass's) readers of this LDS are done
+    for (int t0 = 0; t0 < 2; t0 += PT) {
+        const int64_t row0 = m0 + t0 * 32;
+        {   // residual rows in: 16-B chunks in flat order (a wave instruction covers 1 KB of at most two rows)
+            f32x4 v[PER];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                *reinterpret_cast<f32x4*>(As + r * LN_PARK_LD + feat) = v;
+            for (int k = 0; k < PER; ++k) {
+                const int f = tid + NT * k, row = f / 96, c = f - row * 96;
+                int64_t g = row0 + row;
+                g = g < T ? g : T - 1;
+                v[k] = *reinterpret_cast<const f32x4*>(x + g * 384 + c * 4);
             }
-        __syncthreads();
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = q * 8 + rr;
-            const int64_t tok = m0 + tt * 32 + row;
-            if (tok < T) {  // wave-uniform
-                float v[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) v[j] = As[row * LN_PARK_LD + lane + 64 * j] + x[tok * 384 + lane + 64 * j];
-                ln_row<384, true>(v, gam, bet, eps, x + tok * 384, xh + tok * 384, xl + tok * 384, lane);
+            for (int k = 0; k < PER; ++k) {
+                const int f = tid + NT * k, row = f / 96, c = f - row * 96;
+                *reinterpret_cast<f32x4*>(stage + row * LN_LD + c * 4) = v[k];
             }
         }
+        sync();
+        float part[PT];
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) part[p] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(stage + (p * 32 + r) * LN_LD + feat);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = fmaf(acc[i][t0 + p][4 * g + j], WT_UNSCALE, b[j]) + xv[j];
+                            acc[i][t0 + p][4 * g + j] = v;
+                            part[p] = part[p] + v;
+                        }
+                    }
+                }
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                part[p] = part[p] + __shfl_xor(part[p], 32, 64);  // Pq (a + b == b + a exactly: both halves hold the same bits)
+                if (h == 0) red[(p * 32 + r) * 4 + q] = part[p];
+            }
+        }
+        sync();
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + (p * 32 + r) * 4);
+                const float mean = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
+                float sq = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float d = acc[i][t0 + p][e] - mean;
+                        acc[i][t0 + p][e] = d;
+                        sq = fmaf(d, d, sq);
+                    }
+                sq = sq + __shfl_xor(sq, 32, 64);
+                if (h == 0) red[ROWS * 4 + (p * 32 + r) * 4 + q] = sq;
+            }
+        }
+        sync();
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ROWS * 4 + (p * 32 + r) * 4);
+                const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
+                const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + feat);
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + feat);
+                        f32x4 y;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][t0 + p][4 * g + j] * rstd, gm[j], bt[j]);
+                        *reinterpret_cast<f32x4*>(stage + (p * 32 + r) * LN_LD + feat) = y;
+                    }
+            }
+        }
+        sync();
+        {   // normalised rows out, flat: fp32 x (16 B per thread) and its two f16 planes (8 B each)
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int f = tid + NT * k, row = f / 96, c = f - row * 96;
+                const int64_t g = row0 + row;
+                if (g < T) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
+                    half4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 a, d;
+                        split_act(y[j], a, d);
+                        hi[j] = a;
+                        lo[j] = d;
+                    }
+                    *reinterpret_cast<f32x4*>(x + g * 384 + c * 4) = y;
+                    *reinterpret_cast<half4*>(xh + g * 384 + c * 4) = hi;
+                    *reinterpret_cast<half4*>(xl + g * 384 + c * 4) = lo;
+                }
+            }
+        }
+        if (t0 + PT < 2) sync();  // the stage is rewritten by the next pass
     }
+}
+
+// The unfused form of the same LayerNorm (small batches; ICREC_FUSE=0): x <- LN(a + x) with the reduction order of
+// wt_ln_staged.  8 threads per token: thread (q, h) sums its 48 values in (i, g, j) order, the 8 partials are
+// combined by shuffles in the fixed tree.  `a` already holds dense(.) + bias.
+__global__ __launch_bounds__(256) void add_ln_wt_kernel(const float* __restrict__ a, float* __restrict__ x, int T,
+                                                        const float* __restrict__ gam, const float* __restrict__ bet,
+                                                        float eps, _Float16* __restrict__ xh,
+                                                        _Float16* __restrict__ xl) {
+    const int tid = threadIdx.x, slot = tid & 7, q = slot >> 1, h = slot & 1;
+    int64_t tok = (int64_t)blockIdx.x * 32 + (tid >> 3);
+    const bool ok = tok < T;
+    tok = ok ? tok : (int64_t)T - 1;
+    f32x4 v[3][4];
+    float part = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t at = tok * 384 + q * 96 + i * 32 + 8 * g + 4 * h;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + at);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + at);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[i][g][j] = av[j] + xv[j];
+                part = part + v[i][g][j];
+            }
+        }
+    const int base = (tid & 63) & ~7;  // first lane of this token's 8 threads
+    auto tree = [&](float p) {  // ((P0 + P1) + P2) + P3 with Pq = part(q,0) + part(q,1); every lane gets the same bits
+        p = p + __shfl_xor(p, 1, 64);
+        const float p0 = __shfl(p, base, 64), p1 = __shfl(p, base + 2, 64), p2 = __shfl(p, base + 4, 64),
+                    p3 = __shfl(p, base + 6, 64);
+        return ((p0 + p1) + p2) + p3;
+    };
+    const float mean = tree(part) / 384.0f;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][g][j] - mean;
+                v[i][g][j] = d;
+                sq = fmaf(d, d, sq);
+            }
+    const float var = tree(sq) / 384.0f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + feat);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + feat);
+            f32x4 y;
+            half4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = fmaf(v[i][g][j] * rstd, gm[j], bt[j]);
+                _Float16 p, c;
+                split_act(y[j], p, c);
+                hi[j] = p;
+                lo[j] = c;
+            }
+            if (ok) {
+                *reinterpret_cast<f32x4*>(x + tok * 384 + feat) = y;
+                *reinterpret_cast<half4*>(xh + tok * 384 + feat) = hi;
+                *reinterpret_cast<half4*>(xl + tok * 384 + feat) = lo;
+            }
+        }
 }
 
 // Attention-output projection + residual + LayerNorm in one kernel (large batches): block = 64 tokens x all 384
@@ -274,13 +486,14 @@ __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __
                                                               _Float16* __restrict__ xh, _Float16* __restrict__ xl,
                                                               const float* __restrict__ gam,
                                                               const float* __restrict__ bet, float eps) {
-    constexpr int SM = XRing<2>::BYTES > LN_PARK_BYTES ? XRing<2>::BYTES : LN_PARK_BYTES;
+    constexpr int SM = XRing<2>::BYTES > LnStage<1>::BYTES ? XRing<2>::BYTES : LnStage<1>::BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM];
     const int q = wave_uniform(threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     f32x16 acc[3][2];
-    wt_kloop<3, 2, D>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);
-    wt_ln_epilogue<2>(acc, bias, x, xh, xl, m0, T, gam, bet, eps, smem);
+    wt_kloop<3, 2, D>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
+    wt_ln_staged<1, 256>(acc, true, q, bias, x, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); });
+    ICREC_STAMP(0, 30);
 }
 
 // ---------------------------------------------------------------- fused FFN (large batches)
@@ -310,7 +523,7 @@ constexpr int FFN2_HPLANE = 64 * 256;                    // [64 tokens][128 k] h
 constexpr int FFN2_HBUF = 2 * FFN2_HPLANE;               // hi, lo
 constexpr int FFN2_LDS = FFN2_X_BYTES + 2 * FFN2_HBUF;   // 163,840 B = the whole LDS of a CU
 static_assert(FFN2_LDS == 160 * 1024, "fused FFN LDS budget");
-static_assert(64 * LN_PARK_LD * 4 <= FFN2_LDS, "LN parking area");
+static_assert(LnStage<2>::BYTES <= FFN2_LDS, "LayerNorm stage");
 
 __device__ __forceinline__ void bar_lds() {  // LDS hand-off barrier that leaves global loads in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -334,6 +547,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     const int NC = I / FFN_IC, KS2 = I / 16;
 
+    ICREC_STAMP(0, 0);
+    ICREC_STAMP(4, 0);
     // ---- the block's activation planes -> LDS, once (16-B chunk c of token row t at sub-row c >> 4, slot (c ^ t) & 15)
     {
         u32x4 vh[6], vl[6];
@@ -374,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
             for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
         }
         __syncthreads();  // X resident
+        ICREC_STAMP(0, 1);
         // Software pipeline: iteration c runs P1(c) with the GELU of chunk c-1 spread over its k-steps (one group
         // of 4 intermediates x 1 token tile every third k-step), so the producer's VALU work sits between its own
         // MFMAs and the consumers' instead of behind them.  H[c-1] is handed over at the end of iteration c.
@@ -403,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
                 for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
             char* const Hb = Hs + ((c + 1) & 1) * FFN2_HBUF;  // H[(c - 1) & 1]
             half8 fh[2][2], fl[2][2];  // the next k-step's fragments are read under the current one's MFMAs
+            half4 ghi, glo;            // the GELU group being assembled
             if (MMA) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
@@ -427,21 +644,35 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
                         else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
                     }
                 }
-                if (ks % 3 == 0) {  // G group ks/3 of the PREVIOUS chunk: bias + erf-GELU + split, one 8-byte LDS write per plane
-                    const int gi = ks / 3, g = gi >> 1, tt = gi & 1;
-                    half4 hi, lo;
+                if (ks % 3 != 2) {  // G of the PREVIOUS chunk, two elements per k-step (16 of the 24 k-steps carry a slice):
+                                    // bias + erf-GELU + split; a finished group of 4 consecutive k goes out as one
+                                    // 8-byte LDS write per plane
+                    constexpr int dummy_ = 0;
+                    (void)dummy_;
+                    const int u = ks - ks / 3;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int n = 2 * u + jj, gi = n >> 2, j = n & 3, g = gi >> 1, tt = gi & 1;
                         _Float16 a, d;
                         const float pre = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
                         split_act((VAR & 1) ? pre : gelu_erf_fast(pre), a, d);
-                        hi[j] = a;
-                        lo[j] = d;
+                        ghi[j] = a;
+                        glo[j] = d;
                     }
-                    const int tok = tt * 32 + r;
-                    const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
-                    *reinterpret_cast<half4*>(Hb + pos) = hi;  // iteration 0 writes GELU(0) into a buffer nobody reads yet
-                    *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = lo;
+                    if (u & 1) {
+                        const int gi = u >> 1, g = gi >> 1, tt = gi & 1;
+                        const int tok = tt * 32 + r;
+                        const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
+                        *reinterpret_cast<half4*>(Hb + pos) = ghi;  // iteration 0 writes GELU(0) into a buffer nobody reads yet
+                        *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = glo;
+                    }
+                    if (MMA && !(VAR & 32)) {  // one MFMA, then a dozen of the slice's VALU instructions, six times
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // pin the prefetch (and the GELU slice) to its k-step
             }
@@ -452,10 +683,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
         };
         for (int c = 0; c < NC; ++c) {
             iteration(c, std::true_type{});
+            ICREC_STAMP(0, 2 + 2 * c);
             if (c > 0) bar_lds();  // B(c): H[c - 1] is complete; the consumers have left H[c & 1]
+            ICREC_STAMP(0, 3 + 2 * c);
         }
         iteration(NC, std::false_type{});
         bar_lds();  // B(NC): H[NC - 1]
+        ICREC_STAMP(0, 26);
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -473,8 +707,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
 #pragma unroll
         for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
         __syncthreads();  // X resident (matches the producers' first barrier)
+        ICREC_STAMP(4, 1);
         bar_lds();        // B1: H[0] is ready
         for (int c = 0; c < NC; ++c) {
+            ICREC_STAMP(4, 2 + 2 * c);
             const char* const Hb = Hs + (c & 1) * FFN2_HBUF;
             half8 fh[2][2], fl[2][2];
 #pragma unroll
@@ -501,48 +737,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
                 }
                 __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
             }
+            ICREC_STAMP(4, 3 + 2 * c);
             if (c + 1 < NC) bar_lds();  // B(c+2): done with H[c & 1]; H[(c + 1) & 1] is ready
         }
     }
-    // ---- residual + LayerNorm: consumers park all 64 rows (the X / H areas are free now), every wave normalises 8
-    // rows whose residual values were requested before the hand-off barrier
-    float* As = reinterpret_cast<float*>(smem2);
-    float xres[8][6];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        int64_t tok = m0 + wave * 8 + rr;
-        tok = tok < T ? tok : (int64_t)T - 1;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) xres[rr][j] = x[tok * 384 + lane + 64 * j];
-    }
-    __syncthreads();
-    if (!producer) {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + feat);
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaf(Y[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                    *reinterpret_cast<f32x4*>(As + (tt * 32 + r) * LN_PARK_LD + feat) = v;
-                }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = wave * 8 + rr;
-        const int64_t tok = m0 + row;
-        if (tok < T) {  // wave-uniform
-            float v[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) v[j] = As[row * LN_PARK_LD + lane + 64 * j] + xres[rr][j];
-            ln_row<384, true>(v, gam, bet, eps, x + tok * 384, xh + tok * 384, xl + tok * 384, lane);
-        }
-    }
+    ICREC_STAMP(0, 27);
+    ICREC_STAMP(4, 27);
+    // ---- residual + LayerNorm on the consumers' accumulators (the producers only join the two barriers)
+    __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm stage
+    wt_ln_staged<2, 512>(Y, !producer, q, b2, x, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); });
+    ICREC_STAMP(0, 30);
+    ICREC_STAMP(4, 30);
 }
 
 // W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.
@@ -1227,15 +1432,15 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                                    L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
             } else {
                 launch_wt_linear<0>(ch, cl, T, H, L.Wo_p, H, L.bo, t1, nullptr, nullptr, st);
-                hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g1, L.b1n,
-                                   c.ln_eps, xh, xl);
+                hipLaunchKernelGGL(add_ln_wt_kernel, dim3((T + 31) / 32), dim3(256), 0, st, t1, x, T, L.g1, L.b1n, c.ln_eps,
+                                   xh, xl);
                 {
                     ScopedTimer tm(T_FFN_UP, st);
                     launch_wt_linear<1>(xh, xl, T, H, L.W1_p, I, L.b1, nullptr, hh, hl, st);
                 }
                 launch_wt_linear<0>(hh, hl, T, I, L.W2_p, H, L.b2, t1, nullptr, nullptr, st);
-                hipLaunchKernelGGL((add_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, t1, x, T, L.g2, L.b2n,
-                                   c.ln_eps, xh, xl);
+                hipLaunchKernelGGL(add_ln_wt_kernel, dim3((T + 31) / 32), dim3(256), 0, st, t1, x, T, L.g2, L.b2n, c.ln_eps,
+                                   xh, xl);
             }
         } else {
             launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);

@@ -126,6 +126,18 @@ __device__ __forceinline__ void w_load(half8 (&wh)[NTW], half8 (&wl)[NTW], const
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// In-kernel phase stamps for tools/ffn_bench.hip (diagnostic builds only: -DICREC_STAMPS; the product never defines it).
+#ifdef ICREC_STAMPS
+__device__ unsigned long long g_stamps[1 << 22];
+#define ICREC_STAMP(slot_wave, k)                                                                        \
+    do {                                                                                                 \
+        if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) == (slot_wave))                           \
+            g_stamps[((size_t)blockIdx.x * 2 + ((slot_wave) ? 1 : 0)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ICREC_STAMP(slot_wave, k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- whole-K loop of one output tile
 // acc[i][tt] = sum_k W[(nt0 + i) tile][k] . X[m0 + tt tile][k], K in slabs of 64 (4 k-steps); weight fragments
 // D k-steps ahead in registers (D divides 4), the next activation slab one slab ahead in registers, two LDS
@@ -135,6 +147,7 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
                                          const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, int64_t m0,
                                          int64_t T, char* smem) {
     static_assert(D == 1 || D == 2 || D == 4, "prefetch depth must divide the 4 k-steps of a slab");
+    ICREC_STAMP(0, 0);
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const unsigned lo8 = lane * 8;
     const int KS = K / 16, nslab = K / 64;
@@ -155,6 +168,7 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
     x_store<TTW>(xr, smem);
     if (nslab > 1) x_load<TTW>(xr, Xh, Xl, m0, T, K, 1);
     __syncthreads();
+    ICREC_STAMP(0, 1);
     for (int s = 0; s < nslab; ++s) {
         const char* st = smem + (s & 1) * XRing<TTW>::STAGE_BYTES;
         half8 xh[2][TTW], xl[2][TTW];  // fragments of the next k-step are read under the current one's MFMAs
@@ -183,6 +197,7 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
             if (s + 2 < nslab) x_load<TTW>(xr, Xh, Xl, m0, T, K, s + 2);
         }
         __syncthreads();
+        if (s < 24) ICREC_STAMP(0, 2 + s);
     }
 }
 

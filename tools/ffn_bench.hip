@@ -74,6 +74,45 @@ int main(int argc, char** argv) {
     fill_float<<<8, 256>>>(g, H, 11, 0.1f); fill_float<<<8, 256>>>(bn, H, 12, 0.04f);
     hipDeviceSynchronize();
 
+#ifdef ICREC_STAMPS
+    // phase stamps (s_memtime shader-clock ticks): median over blocks of each interval
+    auto dump = [&](const char* name, int nblocks, int which, std::vector<int> ks) {
+        std::vector<unsigned long long> hs((size_t)nblocks * 64);
+        hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_stamps), hs.size() * 8);
+        printf("%s: median cycles between stamps", name);
+        for (size_t a = 0; a + 1 < ks.size(); ++a) {
+            std::vector<long long> d;
+            for (int b = 0; b < nblocks; ++b) {
+                const unsigned long long t0 = hs[((size_t)b * 2 + which) * 32 + ks[a]], t1 = hs[((size_t)b * 2 + which) * 32 + ks[a + 1]];
+                d.push_back((long long)(t1 - t0));
+            }
+            std::sort(d.begin(), d.end());
+            printf(" [%d->%d] %lld", ks[a], ks[a + 1], d[d.size() / 2]);
+        }
+        std::vector<long long> dur; unsigned long long mn = ~0ull, mx = 0;
+        for (int b = 0; b < nblocks; ++b) { unsigned long long t0 = hs[((size_t)b * 2 + which) * 32 + ks.front()], t1 = hs[((size_t)b * 2 + which) * 32 + ks.back()]; dur.push_back((long long)(t1 - t0)); mn = std::min(mn, t0); mx = std::max(mx, t1); }
+        std::sort(dur.begin(), dur.end());
+        printf("  | block median %lld p90 %lld, kernel span %llu\n", dur[dur.size() / 2], dur[dur.size() * 9 / 10], mx - mn);
+    };
+    {
+        const int T = 131072, nb = T / 64;
+        auto kern = ffn_fused2_kernel<0>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, x, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+        hipDeviceSynchronize();
+        dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 30});
+        dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 30});
+        reinit();
+        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
+        hipDeviceSynchronize();
+        dump("qkv wave0", nb * 3, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
+        hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
+        hipDeviceSynchronize();
+        dump("attn-out+LN wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
+        reinit();
+        return 0;
+    }
+#endif
     for (int T : {T0, 131072, 16384}) {
         const double ffn_flops = 4.0 * T * H * I;
         printf("---- T = %d tokens (%d blocks of 64)\n", T, (T + 63) / 64);
