@@ -205,6 +205,16 @@ ICREC_API int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists,
                      int64_t* out_idx_dev, float* out_score_dev,
                      int device, void* stream);
 
+/* Complete ranking of the catalog for each query: what `scores.argsort(descending=True)` returns in the reference's
+ * offline evaluation consumers (src/baselines/content_based.py:58-63, scripts/compare_untrained_vs_trained.py:74-85).
+ *   out_rows_dev int64[n_queries, n_rows]  row_offset + row, best first: score descending, lower row first on ties
+ * (torch.argsort is unstable on ties; this is the library's total order, the same as icrec_search's).  The exact
+ * score rows are materialised in the workspace (n_queries * n_rows * 12..20 bytes): callers stream queries in
+ * passes (256 queries over 49,688 rows = 0.2 GB).  Not on the serving path.                                       */
+ICREC_API size_t icrec_rank_all_workspace_bytes(const icrec_index* idx, int32_t n_queries);
+ICREC_API int icrec_rank_all(icrec_index* idx, const float* q_dev, int32_t n_queries, int64_t* out_rows_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Full score row(s) for parity checks: out[n_queries, n_rows] = q_hat . p_hat.
  * Not on the serving path (the serving kernels never materialise scores).    */
 ICREC_API int icrec_scores(icrec_index* idx, const float* q_dev, int32_t n_queries,

@@ -27,7 +27,7 @@ EXPORTS = [
     "icrec_comm_unique_id", "icrec_comm_init", "icrec_comm_destroy", "icrec_comm_rank", "icrec_comm_world",
     "icrec_search_sharded_workspace_bytes", "icrec_search_sharded",
     "icrec_search_workspace_bytes", "icrec_search", "icrec_search_partial", "icrec_merge_topk",
-    "icrec_scores", "icrec_normalize_rows",
+    "icrec_scores", "icrec_normalize_rows", "icrec_rank_all_workspace_bytes", "icrec_rank_all",
     "icrec_tokenizer_create", "icrec_tokenizer_destroy", "icrec_tokenizer_vocab_size", "icrec_tokenize",
     "icrec_last_error", "icrec_version",
     "icrec_timing_enable", "icrec_timing_reset", "icrec_timing_query",
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
         "icrec_search_partial": (C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]),
         "icrec_merge_topk": (C.c_int, [vp, i32, i32, i32, vp, vp, C.c_int, vp]),
         "icrec_scores": (C.c_int, [vp, vp, i32, vp, vp, sz, vp]),
+        "icrec_rank_all_workspace_bytes": (sz, [vp, i32]),
+        "icrec_rank_all": (C.c_int, [vp, vp, i32, vp, vp, sz, vp]),
         "icrec_normalize_rows": (C.c_int, [vp, vp, i64, i32, C.c_float, C.c_int, vp]),
         "icrec_tokenizer_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
         "icrec_tokenizer_destroy": (C.c_int, [vp]),

@@ -666,7 +666,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
                         *reinterpret_cast<half4*>(Hb + pos) = ghi;  // iteration 0 writes GELU(0) into a buffer nobody reads yet
                         *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = glo;
                     }
-                    if (MMA && !(VAR & 32)) {  // one MFMA, then a dozen of the slice's VALU instructions, six times
+                    if (MMA && !(VAR & 32)) {  // the next step's LDS reads first; then one MFMA and a dozen of the slice's VALU
+                                               // instructions, six times
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                         for (int m = 0; m < 6; ++m) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1196,6 +1198,7 @@ struct LayerW {
 struct Encoder {
     icrec_bert_cfg cfg;
     int device = 0;
+    int n_cu = 256;
     float* blob = nullptr;      // the uploaded weight blob
     float* extra = nullptr;     // repacked Wqkv / bqkv
     _Float16* planes = nullptr; // packed weight fragments (F16X3)
@@ -1306,6 +1309,7 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     Encoder* e = new Encoder();
     e->cfg = *cfg;
     e->device = device;
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t H = cfg->hidden, I = cfg->intermediate;
     const size_t mat_per_layer = 3 * H * H + H * H + I * H + H * I;
     const bool x3 = cfg->gemm_mode == ICREC_GEMM_F16X3;
@@ -1400,6 +1404,13 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const int H = c.hidden, I = c.intermediate;
     const int rows_grid = (T + 3) / 4;
     const bool x3 = c.gemm_mode == ICREC_GEMM_F16X3;
+    // whole rounds of the fused FFN kernel (one 64-token workgroup per CU) + a short remainder, see the layer loop
+    const int round_tokens = 64 * e->n_cu;
+    int T_main = T, T_tail = 0;
+    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= X3_SMALL_M) {
+        T_tail = T % round_tokens;
+        T_main = T - T_tail;
+    }
     const char* fuse_env = getenv("ICREC_FUSE");  // ICREC_FUSE=0: A/B switch to the unfused kernels (read per call: tests flip it)
     const bool fuse = !(fuse_env && fuse_env[0] == '0');
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
@@ -1419,29 +1430,48 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& L = e->layers[l];
         if (x3) {
-            launch_wt_linear<0>(xh, xl, T, H, L.Wqkv_p, 3 * H, L.bqkv, qkv, nullptr, nullptr, st);
-            launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
-            if (T > X3_SMALL_M && fuse) {
-                // attention-out + residual + LN, then the whole FFN block + residual + LN: two kernels per half layer
-                hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, st, ch, cl, T, H, L.Wo_p,
-                                   L.bo, x, xh, xl, L.g1, L.b1n, c.ln_eps);
-                ScopedTimer tm(T_FFN_UP, st);
-                auto kern = ffn_fused2_kernel<0>;
-                if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
-                hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, st, x, xh, xl, T, I, L.W1_p, L.b1,
-                                   L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
-            } else {
-                launch_wt_linear<0>(ch, cl, T, H, L.Wo_p, H, L.bo, t1, nullptr, nullptr, st);
-                hipLaunchKernelGGL(add_ln_wt_kernel, dim3((T + 31) / 32), dim3(256), 0, st, t1, x, T, L.g1, L.b1n, c.ln_eps,
-                                   xh, xl);
-                {
+            // Token ranges: [0, T_main) goes through the batch kernels in whole rounds of one 64-token workgroup per
+            // CU, a short remainder [T_main, T) through the small-batch kernels (same arithmetic, same bits) instead
+            // of costing every batch kernel an extra, almost empty round.
+            auto qkv_stage = [&](int r0, int Tn) {
+                launch_wt_linear<0>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv,
+                                    qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
+            };
+            auto post_stage = [&](int r0, int Tn) -> int {
+                float* const xr = x + (size_t)r0 * H;
+                float* const t1r = t1 + (size_t)r0 * H;
+                _Float16 *const xhr = xh + (size_t)r0 * H, *const xlr = xl + (size_t)r0 * H;
+                const _Float16 *const chr = ch + (size_t)r0 * H, *const clr = cl + (size_t)r0 * H;
+                if (Tn > X3_SMALL_M && fuse) {
+                    // attention-out + residual + LN, then the whole FFN block + residual + LN: two kernels per half layer
+                    hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((Tn + 63) / 64), dim3(256), 0, st, chr, clr, Tn, H,
+                                       L.Wo_p, L.bo, xr, xhr, xlr, L.g1, L.b1n, c.ln_eps);
                     ScopedTimer tm(T_FFN_UP, st);
-                    launch_wt_linear<1>(xh, xl, T, H, L.W1_p, I, L.b1, nullptr, hh, hl, st);
+                    auto kern = ffn_fused2_kernel<0>;
+                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
+                    hipLaunchKernelGGL(kern, dim3((Tn + 63) / 64), dim3(512), FFN2_LDS, st, xr, xhr, xlr, Tn, I, L.W1_p,
+                                       L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
+                } else {
+                    _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
+                    launch_wt_linear<0>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, nullptr, nullptr, st);
+                    hipLaunchKernelGGL(add_ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, xr, Tn, L.g1, L.b1n,
+                                       c.ln_eps, xhr, xlr);
+                    {
+                        ScopedTimer tm(Tn > X3_SMALL_M ? T_FFN_UP : T_NSLOTS - 1, st);
+                        launch_wt_linear<1>(xhr, xlr, Tn, H, L.W1_p, I, L.b1, nullptr, hhr, hlr, st);
+                    }
+                    launch_wt_linear<0>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, nullptr, nullptr, st);
+                    hipLaunchKernelGGL(add_ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, xr, Tn, L.g2, L.b2n,
+                                       c.ln_eps, xhr, xlr);
                 }
-                launch_wt_linear<0>(hh, hl, T, I, L.W2_p, H, L.b2, t1, nullptr, nullptr, st);
-                hipLaunchKernelGGL(add_ln_wt_kernel, dim3((T + 31) / 32), dim3(256), 0, st, t1, x, T, L.g2, L.b2n, c.ln_eps,
-                                   xh, xl);
-            }
+                return ICREC_OK;
+            };
+            qkv_stage(0, T_main);
+            if (T_tail) qkv_stage(T_main, T_tail);
+            launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            if (int rc_ = post_stage(0, T_main)) return rc_;
+            if (T_tail)
+                if (int rc_ = post_stage(T_main, T_tail)) return rc_;
         } else {
             launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
             launch_attention<false, false>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);

@@ -965,6 +965,80 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     return ICREC_OK;
 }
 
+// ---------------------------------------------------------------- full ranking (offline evaluation consumers)
+// The reference's ContentBasedBaseline.rank_all / compare_untrained_vs_trained (src/baselines/content_based.py:58-63,
+// scripts/compare_untrained_vs_trained.py:74-85) argsort every score row completely.  One workgroup per query sorts the
+// packed keys (orderable(score) << 32 | ~row: the search kernels' total order, score descending then row ascending)
+// with a bitonic network: P = next power of two >= n_rows keys per query in global scratch (pads = key 0, which sorts
+// last), stages with partner distance < 4,096 run on an 8,192-key segment in LDS, the rest in global memory.
+constexpr int RANK_SEG = 8192;  // keys per LDS segment (64 KB)
+__global__ __launch_bounds__(1024) void rank_keys_kernel(const float* __restrict__ scores, int64_t n_rows, int64_t P,
+                                                         u64* __restrict__ keys) {
+    const int64_t qi = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 1024)
+        keys[qi * P + i] = i < n_rows ? make_key(scores[qi * n_rows + i], (uint32_t)i) : 0ull;
+}
+
+// descending bitonic compare-exchange on a[i], a[i ^ j] inside the size-k subsequence containing i
+__device__ __forceinline__ void bitonic_cx(u64& lo_slot, u64& hi_slot, bool desc) {
+    const u64 a = lo_slot, b = hi_slot;
+    const bool swap = desc ? (a < b) : (a > b);
+    lo_slot = swap ? b : a;
+    hi_slot = swap ? a : b;
+}
+
+__global__ __launch_bounds__(1024) void rank_sort_kernel(u64* __restrict__ keys, int64_t P) {
+    __shared__ u64 seg[RANK_SEG];
+    u64* const a = keys + (int64_t)blockIdx.x * P;
+    const int t = threadIdx.x;
+    const int64_t seg_len = P < RANK_SEG ? P : RANK_SEG, nseg = P / seg_len;
+    // the stages j = j_hi, j_hi/2, ..., 1 of size-k merges, for one segment held in LDS (partners stay inside it)
+    auto local_stages = [&](int64_t base, int64_t k_lo, int64_t k_hi, int64_t j_cap) {
+        for (int64_t i = t; i < seg_len; i += 1024) seg[i] = a[base + i];
+        __syncthreads();
+        for (int64_t k = k_lo; k <= k_hi; k <<= 1)
+            for (int64_t j = (k >> 1) < j_cap ? (k >> 1) : j_cap; j >= 1; j >>= 1) {
+                for (int64_t p = t; p < seg_len / 2; p += 1024) {
+                    const int64_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    u64 x = seg[i], y = seg[i | j];
+                    bitonic_cx(x, y, ((base + i) & k) == 0);
+                    seg[i] = x;
+                    seg[i | j] = y;
+                }
+                __syncthreads();
+            }
+        for (int64_t i = t; i < seg_len; i += 1024) a[base + i] = seg[i];
+        __syncthreads();
+    };
+    for (int64_t sidx = 0; sidx < nseg; ++sidx) local_stages(sidx * seg_len, 2, seg_len, seg_len / 2);  // k <= seg_len
+    for (int64_t k = seg_len * 2; k <= P; k <<= 1) {
+        for (int64_t j = k >> 1; j >= seg_len; j >>= 1) {  // partners in different segments: global memory
+            for (int64_t p = t; p < P / 2; p += 1024) {
+                const int64_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                u64 x = a[i], y = a[i | j];
+                bitonic_cx(x, y, (i & k) == 0);
+                a[i] = x;
+                a[i | j] = y;
+            }
+            __syncthreads();  // one workgroup owns the row; the barrier orders its global writes for its own reads
+        }
+        for (int64_t sidx = 0; sidx < nseg; ++sidx) local_stages(sidx * seg_len, k, k, seg_len / 2);
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_emit_kernel(const u64* __restrict__ keys, int64_t n_rows, int64_t P,
+                                                        int64_t row_offset, int64_t* __restrict__ out) {
+    const int64_t qi = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256)
+        out[qi * n_rows + i] = row_offset + (int64_t)key_row(keys[qi * P + i]);
+}
+
+static int64_t rank_pow2(int64_t n) {
+    int64_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
 }  // namespace icrec
 
 using namespace icrec;
@@ -1093,6 +1167,41 @@ int icrec_scores(icrec_index* h, const float* q_dev, int32_t n_queries, float* o
     ICREC_REQUIRE(out_dev, "icrec_scores: NULL output");
     return run_search(reinterpret_cast<Index*>(h), q_dev, n_queries, 1, nullptr, nullptr, nullptr, nullptr, nullptr,
                       out_dev, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t icrec_rank_all_workspace_bytes(const icrec_index* h, int32_t n_queries) {
+    const Index* ix = reinterpret_cast<const Index*>(h);
+    if (!ix || n_queries < 1) return 0;
+    const size_t sw = icrec_search_workspace_bytes(h, n_queries, 1);
+    if (sw == 0) return 0;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al((size_t)n_queries * ix->n_rows * 4) + al((size_t)n_queries * rank_pow2(ix->n_rows) * 8) + al(sw);
+}
+
+int icrec_rank_all(icrec_index* h, const float* q_dev, int32_t n_queries, int64_t* out_rows_dev, void* ws,
+                   size_t ws_bytes, void* stream) {
+    Index* ix = reinterpret_cast<Index*>(h);
+    ICREC_REQUIRE(ix && q_dev && out_rows_dev && n_queries >= 1, "icrec_rank_all: bad argument");
+    const size_t need = icrec_rank_all_workspace_bytes(h, n_queries);
+    if (!ws || ws_bytes < need || need == 0) {
+        set_error("icrec_rank_all: workspace too small (%zu < %zu)", ws_bytes, need);
+        return ICREC_ENOMEM;
+    }
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int64_t P = rank_pow2(ix->n_rows);
+    char* base = reinterpret_cast<char*>(ws);
+    float* scores = reinterpret_cast<float*>(base);
+    u64* keys = reinterpret_cast<u64*>(base + al((size_t)n_queries * ix->n_rows * 4));
+    char* sws = reinterpret_cast<char*>(keys) + al((size_t)n_queries * P * 8);
+    if (int rc = icrec_scores(h, q_dev, n_queries, scores, sws, ws_bytes - (size_t)(sws - base), stream)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((P + 1023) / 1024 < 64 ? (P + 1023) / 1024 : 64);
+    hipLaunchKernelGGL(rank_keys_kernel, dim3(gx, n_queries), dim3(1024), 0, st, scores, ix->n_rows, P, keys);
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(n_queries), dim3(1024), 0, st, keys, P);
+    hipLaunchKernelGGL(rank_emit_kernel, dim3(gx * 4, n_queries), dim3(256), 0, st, keys, ix->n_rows, P, ix->row_offset,
+                       out_rows_dev);
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
 }
 
 int icrec_merge_topk(const uint64_t* keys_dev, int32_t n_lists, int32_t n_queries, int32_t k, int64_t* out_idx_dev,

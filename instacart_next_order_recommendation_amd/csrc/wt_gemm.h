@@ -161,15 +161,19 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][tt][e] = 0.0f;
     half8 wh[D][NTW], wl[D][NTW];
-    u32x4 xr[2 * TTW];
-    x_load<TTW>(xr, Xh, Xl, m0, T, K, 0);
+    // activation slabs: TWO in flight in registers (slab s+1 is written to LDS at the end of slab s, slab s+2 was
+    // requested a whole slab earlier) - with one, every slab boundary waited for an HBM round trip (stamps: the first
+    // slabs of a block took 2x the MFMA time)
+    u32x4 xa[2 * TTW], xb[2 * TTW];
+    x_load<TTW>(xa, Xh, Xl, m0, T, K, 0);
 #pragma unroll
     for (int d = 0; d < D; ++d) w_load<NTW>(wh[d], wl[d], wp, d, lo8);
-    x_store<TTW>(xr, smem);
-    if (nslab > 1) x_load<TTW>(xr, Xh, Xl, m0, T, K, 1);
+    if (nslab > 1) x_load<TTW>(xb, Xh, Xl, m0, T, K, 1);
+    x_store<TTW>(xa, smem);
+    if (nslab > 2) x_load<TTW>(xa, Xh, Xl, m0, T, K, 2);
     __syncthreads();
     ICREC_STAMP(0, 1);
-    for (int s = 0; s < nslab; ++s) {
+    auto slab = [&](int s, u32x4 (&xnext)[2 * TTW]) {  // xnext holds slab s+1 on entry, slab s+3 on exit
         const char* st = smem + (s & 1) * XRing<TTW>::STAGE_BYTES;
         half8 xh[2][TTW], xl[2][TTW];  // fragments of the next k-step are read under the current one's MFMAs
 #pragma unroll
@@ -193,11 +197,15 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
             __builtin_amdgcn_sched_barrier(0);  // keep every prefetch in its k-step (the scheduler otherwise sinks the loads to their uses)
         }
         if (s + 1 < nslab) {  // slab-granular (uniform) branches; the k-step body above is straight-line code
-            x_store<TTW>(xr, smem + ((s + 1) & 1) * XRing<TTW>::STAGE_BYTES);
-            if (s + 2 < nslab) x_load<TTW>(xr, Xh, Xl, m0, T, K, s + 2);
+            x_store<TTW>(xnext, smem + ((s + 1) & 1) * XRing<TTW>::STAGE_BYTES);
+            if (s + 3 < nslab) x_load<TTW>(xnext, Xh, Xl, m0, T, K, s + 3);
         }
         __syncthreads();
         if (s < 24) ICREC_STAMP(0, 2 + s);
+    };
+    for (int s = 0; s < nslab; s += 2) {  // nslab is even (K is a multiple of 128 for every layer of the encoder)
+        slab(s, xb);
+        slab(s + 1, xa);
     }
 }
 

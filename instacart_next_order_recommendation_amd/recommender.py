@@ -116,6 +116,8 @@ class SbertModel:
         self.shape = loaded.shape
         self.device = device
         self.encoder = DeviceEncoder(loaded.weights, loaded.shape, device)
+        self._weights = loaded.weights
+        self._encoder_no_flag: Optional[DeviceEncoder] = None  # normalize_embeddings=False: one normalisation fewer
 
     def encode_to_device(self, texts: Sequence[str], tokens_per_call: int = 1 << 18) -> torch.Tensor:
         """Embeddings [n, 384] left on the GPU (serving path: no host round trip)."""
@@ -127,13 +129,22 @@ class SbertModel:
 
         The reference pads and runs `batch_size` texts per forward; packed varlen batching makes
         the result independent of batch composition, so `batch_size` only bounds tokens per call."""
-        if not normalize_embeddings and self.shape.n_normalize > 1:
-            raise NotImplementedError("normalize_embeddings=False: construct the encoder with n_normalize-1")
         single = isinstance(sentences, str)
         texts = [sentences] if single else list(sentences)
         if not texts:
             return np.zeros((0, self.shape.hidden), np.float32)
-        emb = self.encode_to_device(texts, tokens_per_call=max(int(batch_size), 1) * 4096).cpu().numpy()
+        if normalize_embeddings or self.shape.n_normalize < 1:
+            enc = self.encoder
+        else:
+            # the flag's F.normalize is the LAST of the n_normalize passes the device encoder applies (the
+            # pipeline's own Normalize module, if any, stays): a second encoder configured with one pass fewer
+            if self._encoder_no_flag is None:
+                from dataclasses import replace
+
+                self._encoder_no_flag = DeviceEncoder(self._weights, replace(self.shape, n_normalize=self.shape.n_normalize - 1),
+                                                      self.device, gemm_mode=self.encoder.gemm_mode)
+            enc = self._encoder_no_flag
+        emb = enc.encode_ids(self.tokenizer(texts), max_tokens_per_call=max(int(batch_size), 1) * 4096).cpu().numpy()
         return emb[0] if single else emb
 
 

@@ -155,6 +155,22 @@ class DeviceIndex:
                                                  _stream_ptr(self.device)), "icrec_scores")
         return out
 
+    def rank_all(self, q) -> torch.Tensor:
+        """The complete ranking of the shard for each query: int64 [Q, n_rows] global rows, best first
+        (score descending, lower row first on ties) — `scores.argsort(descending=True)` of the reference's
+        evaluation consumers.  Workspace grows with Q * n_rows: call it in passes of a few hundred queries."""
+        q = self._queries(q)
+        Q = int(q.shape[0])
+        L = _native.lib()
+        need = int(L.icrec_rank_all_workspace_bytes(self._h, Q))
+        if need == 0:
+            raise _native.IcrecError(f"bad rank_all shape: n_queries={Q}")
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((Q, self.n_rows), dtype=torch.int64, device=self.device)
+        _native.check(L.icrec_rank_all(self._h, _ptr(q), Q, _ptr(out), _ptr(ws), ws.numel(), _stream_ptr(self.device)),
+                      "icrec_rank_all")
+        return out
+
     def export(self) -> torch.Tensor:
         """The normalised rows the index holds, [n_rows, dim] fp32 on the device."""
         out = torch.empty((self.n_rows, self.dim), dtype=torch.float32, device=self.device)

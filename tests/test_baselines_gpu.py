@@ -41,3 +41,8 @@ def test_rank_all_matches_oracle_topk(tmp_path):
         assert np.abs(got_sc - want_sc[qi]).max() < 2e-5, qid
     with pytest.raises(ValueError):
         cb.rank_all(depth=129)
+    # the reference's own contract: the COMPLETE order (content_based.py:58-63); its head is the depth-100 list
+    everything = cb.rank_all(queries_per_pass=16)
+    for qid in queries:
+        assert len(everything[qid]) == 300 and set(everything[qid]) == set(corpus)
+        assert everything[qid][:100] == ranked[qid]

@@ -137,3 +137,41 @@ def test_graph_fast_path_equals_plain_path(world, monkeypatch):
     assert len(rec._fast._graphs) >= 4
     monkeypatch.setenv("ICREC_USE_GRAPH", "0")
     assert Recommender(world["model_dir"], world["corpus_path"])._fast is None
+
+
+def test_encode_without_flag_normalisation(world):
+    """SentenceTransformer.encode(normalize_embeddings=False): one normalisation pass fewer.  The synthetic model
+    directory has a Normalize module, so the output is still a unit vector and equals the default up to one
+    division by ~1.0; without that module it would be the raw mean pool."""
+    from instacart_next_order_recommendation_amd.recommender import Recommender
+
+    rec = Recommender(world["model_dir"], world["corpus_path"])
+    texts = ["[+3d w1h10] Organic Milk, Whole Wheat Bread.", "Product: Oat Milk. Aisle: aisle 3. Department: dept tea."]
+    a = rec.model.encode(texts, normalize_embeddings=True)
+    b = rec.model.encode(texts, normalize_embeddings=False)
+    assert a.shape == b.shape == (2, 384)
+    assert np.abs(a - b).max() < 1e-6
+    assert rec.model._encoder_no_flag is not None and rec.model._encoder_no_flag.shape.n_normalize == rec.model.shape.n_normalize - 1
+
+
+def test_cli_runs_demo_query(tmp_path, capsys):
+    """`python -m instacart_next_order_recommendation_amd --config ...` (reference: python -m src.inference)."""
+    import json
+
+    import yaml
+
+    from instacart_next_order_recommendation_amd import cli, synthetic as syn
+    from instacart_next_order_recommendation_amd.model_io import write_synthetic_model_dir
+
+    model_dir = write_synthetic_model_dir(tmp_path / "model", seed=1)
+    corpus = tmp_path / "eval_corpus.json"
+    corpus.write_text(json.dumps(syn.synthetic_catalog(200)))
+    (tmp_path / "eval_queries.json").write_text(json.dumps({"42": "[+1d w2h9] Greek Yogurt, Honey."}))
+    for extra, head in (({}, "No query or eval_query_id"), ({"query": "[+2d w0h8] Oat Milk."}, "Query:"),
+                        ({"eval_query_id": "42"}, "Query (eval_id=42)")):
+        cfg = tmp_path / "inference.yaml"
+        cfg.write_text(yaml.safe_dump({"model_dir": str(model_dir), "corpus": str(corpus), "use_index": False,
+                                       "top_k": 3, "corpus_hf_repo": "ignored/offline", **extra}))
+        cli.main(["--config", str(cfg)])
+        out = capsys.readouterr().out
+        assert head in out and "Top-3 recommendations:" in out and out.count("product_id=") == 3

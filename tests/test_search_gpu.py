@@ -397,3 +397,30 @@ def test_bf16_filter_index_is_bit_identical_to_bf16_exact(torch_cuda, nq, k, n):
     np.testing.assert_array_equal(idx.cpu().numpy(), want_i)
     np.testing.assert_array_equal(sc.cpu().numpy(), want_s)
     np.testing.assert_array_equal(ix.export().cpu().numpy(), _oracle().round_bf16(_oracle().normalize_rows(P)))
+
+
+@pytest.mark.parametrize("n,nq,storage", [(49_688, 5, "f32"), (1000, 3, "f32"), (8192, 2, "f32"), (20_001, 4, "bf16"), (7, 2, "f32")])
+def test_rank_all_full_order_vs_oracle(torch_cuda, n, nq, storage):
+    """icrec_rank_all = the complete argsort(descending) of every score row under the library's total order:
+    bit-exact scores (oracle) sorted by (score desc, row asc), duplicate rows included."""
+    torch = torch_cuda
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.search import DeviceIndex
+    from oracle import oracle
+
+    P = syn.synthetic_embeddings(n, 384, seed=31)
+    if n > 100:
+        P[17] = P[3]          # exact ties
+        P[n - 1] = P[3]
+    q = syn.synthetic_embeddings(nq, 384, seed=32)
+    ix = DeviceIndex(P, storage=storage, row_offset=1000)
+    got = ix.rank_all(torch.from_numpy(q).cuda()).cpu().numpy()
+    assert got.shape == (nq, n)
+    Pn = oracle.normalize_rows(P)
+    if storage == "bf16":
+        Pn = oracle.round_bf16(Pn)
+    sc = oracle.scores(oracle.normalize_rows(q), Pn)
+    for i in range(nq):
+        want = np.lexsort((np.arange(n), -sc[i].astype(np.float64)))  # score desc, row asc
+        np.testing.assert_array_equal(got[i] - 1000, want)
+    ix.close()
