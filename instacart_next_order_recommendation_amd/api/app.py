@@ -10,9 +10,12 @@ src/api/auth.py:39-71 (X-API-Key / Bearer).  Differences, all deliberate:
   * feedback endpoints are out of scope.
 Env: MODEL_DIR, CORPUS_PATH, API_KEY, INFERENCE_DEVICE, MAX_CORPUS_UPLOAD_PRODUCTS,
      BATCH_MAX_SIZE (256), BATCH_MAX_WAIT_MS (2).
+     ICREC_GPU_WORKER_SOCKET: this process is an HTTP front-end of the multi-process server (serve.py): it loads
+     the corpus JSON only and forwards every request to the GPU-owner process (worker.py).
 """
 from __future__ import annotations
 
+import asyncio
 import json
 import logging
 import os
@@ -44,12 +47,26 @@ def _env_path(name: str, default: str) -> Path:
     return Path(os.getenv(name) or default)
 
 
-def _install(app: FastAPI, recommender, corpus_path) -> None:
+def _install(app: FastAPI, recommender, corpus_path, batcher=None) -> None:
+    """Swap in a recommender + its batcher (plain attribute stores: a request sees either the old pair or the new)."""
+    batcher = batcher or MicroBatcher(recommender, max_batch=int(os.getenv("BATCH_MAX_SIZE", "256")),
+                                      max_wait_ms=float(os.getenv("BATCH_MAX_WAIT_MS", "2")))
+    app.state.batcher = batcher
     app.state.recommender = recommender
     app.state.corpus_path = corpus_path
-    app.state.batcher = MicroBatcher(recommender, max_batch=int(os.getenv("BATCH_MAX_SIZE", "256")),
-                                     max_wait_ms=float(os.getenv("BATCH_MAX_WAIT_MS", "2")))
     app.state.eval_queries_cache = None
+
+
+def _install_frontend(app: FastAPI, sock_path: str, corpus_path) -> None:
+    """Front-end of the multi-process server: corpus texts only + a socket to the GPU worker."""
+    from .remote import CorpusView, RemoteBatcher
+
+    def on_corpus(new_path: str) -> None:  # the worker re-indexed (another front-end's /admin/corpus): reload texts
+        app.state.recommender = CorpusView(new_path)
+        app.state.corpus_path = Path(new_path)
+        app.state.eval_queries_cache = None
+
+    _install(app, CorpusView(corpus_path), corpus_path, RemoteBatcher(sock_path, on_corpus))
 
 
 @asynccontextmanager
@@ -57,9 +74,12 @@ async def lifespan(app: FastAPI) -> AsyncIterator[None]:
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     model_dir = _env_path("MODEL_DIR", "models/two_tower_sbert/final")
     corpus_path = _env_path("CORPUS_PATH", "processed/p5_mp20_ef0.1/eval_corpus.json")
-    logger.info("Loading recommender model_dir=%s corpus=%s", model_dir, corpus_path)
-    recommender = MonitoredRecommender(model_dir=model_dir, corpus_path=corpus_path)
-    _install(app, recommender, corpus_path)
+    sock_path = os.getenv("ICREC_GPU_WORKER_SOCKET")
+    if sock_path:
+        _install_frontend(app, sock_path, corpus_path)
+    else:
+        logger.info("Loading recommender model_dir=%s corpus=%s", model_dir, corpus_path)
+        _install(app, MonitoredRecommender(model_dir=model_dir, corpus_path=corpus_path), corpus_path)
     app.state.ready = True
     MODEL_LOADED.set(1)
     try:
@@ -198,7 +218,7 @@ async def recommend_endpoint(payload: RecommendationRequest, request: Request,
             t_submit = time.time()
             results, tm = await batcher.submit(retrieval_query, payload.top_k, exclude_ids)
             RECOMMENDATION_BATCH_SIZE.observe(tm.batch_size)
-            if isinstance(recommender, _MonitoredType):
+            if isinstance(recommender, _MonitoredType) or getattr(recommender, "reports_stats", False) is True:
                 n = len(results)
                 stats = InferenceStatistics(
                     total_latency_ms=(time.time() - t_submit) * 1000, query_embedding_time_ms=tm.encode_ms,
@@ -238,16 +258,31 @@ async def corpus_upload_endpoint(payload: CorpusUploadRequest, request: Request,
         raise HTTPException(status_code=status.HTTP_413_REQUEST_ENTITY_TOO_LARGE,
                             detail=f"corpus has {len(payload.corpus)} products; limit is {limit}")
     current = getattr(request.app.state, "recommender", None)
-    model_dir = getattr(current, "model_dir", None) or _env_path("MODEL_DIR", "models/two_tower_sbert/final")
     tmp_dir = Path(tempfile.mkdtemp(prefix="icrec_corpus_"))
     corpus_path = tmp_dir / "eval_corpus.json"
     corpus_path.write_text(json.dumps(payload.corpus))
+    old = getattr(request.app.state, "batcher", None)
     try:
-        new_rec = MonitoredRecommender(model_dir=model_dir, corpus_path=corpus_path)
+        if getattr(current, "remote", False) is True:
+            # multi-process server: the GPU worker re-encodes (in a thread of its own, still serving the old catalog)
+            # and swaps; every front-end then reloads the texts (this one right here, the others on the broadcast)
+            await old.reindex(str(corpus_path))
+            from .remote import CorpusView
+
+            request.app.state.recommender = CorpusView(corpus_path)
+            request.app.state.corpus_path = corpus_path
+            request.app.state.eval_queries_cache = None
+            return CorpusUploadResponse(status="ok", n_products=len(payload.corpus))
+        model_dir = getattr(current, "model_dir", None) or _env_path("MODEL_DIR", "models/two_tower_sbert/final")
+        # the full GPU re-encode runs in a worker thread: requests keep being served from the old recommender
+        # (the reference builds it inline and stalls its event loop, routes/corpus.py:87-98), then one swap
+        new_rec = await asyncio.get_running_loop().run_in_executor(
+            None, lambda: MonitoredRecommender(model_dir=model_dir, corpus_path=corpus_path))
+    except HTTPException:
+        raise
     except Exception as exc:  # noqa: BLE001
         raise HTTPException(status_code=status.HTTP_500_INTERNAL_SERVER_ERROR,
                             detail=f"Failed to load corpus: {exc}") from exc
-    old = getattr(request.app.state, "batcher", None)
     _install(request.app, new_rec, corpus_path)
     if old is not None:
         await old.stop()

@@ -1,0 +1,97 @@
+"""Front-end side of the multi-process server: what `app.state.recommender` / `app.state.batcher` are in a
+process that does not own the GPU (ICREC_GPU_WORKER_SOCKET set).  See worker.py for the protocol."""
+from __future__ import annotations
+
+import asyncio
+import itertools
+import json
+from pathlib import Path
+from typing import Optional
+
+from .batcher import BatchTimings
+from .worker import frame, read_frame
+
+
+class CorpusView:
+    """The attributes the routes read from a recommender (pid_to_text, corpus_path, product_ids) loaded from the
+    corpus JSON alone — no model, no GPU (reference: Recommender._load_corpus, serve_recommendations.py:158-164)."""
+
+    reports_stats = True   # the worker runs a MonitoredRecommender: responses carry `stats`
+    remote = True
+
+    def __init__(self, corpus_path):
+        self.corpus_path = Path(corpus_path).resolve()
+        with open(self.corpus_path) as f:
+            corpus = json.load(f)
+        self.product_ids = list(corpus.keys())
+        self.pid_to_text = corpus
+        self.model_dir = None
+
+    def recommend_batch(self, *a, **k):  # pragma: no cover - marks the object as batch-capable for the route
+        raise RuntimeError("front-end processes forward to the GPU worker")
+
+
+class RemoteBatcher:
+    """MicroBatcher's `submit` interface over the worker socket."""
+
+    def __init__(self, sock_path: str, on_corpus=None):
+        self.sock_path = sock_path
+        self._reader: Optional[asyncio.StreamReader] = None
+        self._writer: Optional[asyncio.StreamWriter] = None
+        self._pending: dict[int, asyncio.Future] = {}
+        self._ids = itertools.count(1)
+        self._task: Optional[asyncio.Task] = None
+        self._on_corpus = on_corpus
+        self._lock = asyncio.Lock()
+
+    async def start(self) -> None:
+        async with self._lock:
+            if self._writer is None:
+                self._reader, self._writer = await asyncio.open_unix_connection(self.sock_path, limit=1 << 26)
+                self._task = asyncio.create_task(self._read_loop())
+
+    async def stop(self) -> None:
+        if self._task is not None:
+            self._task.cancel()
+            self._task = None
+        if self._writer is not None:
+            self._writer.close()
+            self._writer = None
+
+    async def _read_loop(self) -> None:
+        try:
+            while True:
+                msg = await read_frame(self._reader)
+                kind, rid = msg[0], msg[1]
+                if kind == "corpus" and self._on_corpus is not None:
+                    self._on_corpus(msg[2])
+                fut = self._pending.pop(rid, None) if rid is not None else None
+                if fut is None or fut.done():
+                    continue
+                if kind == "ok":
+                    fut.set_result(([(p, float(s)) for p, s in msg[2]], BatchTimings(int(msg[5]), msg[3], msg[4], 0.0)))
+                elif kind == "corpus":
+                    fut.set_result((msg[2], int(msg[3])))
+                else:
+                    fut.set_exception(RuntimeError(msg[2]))
+        except (asyncio.IncompleteReadError, ConnectionResetError, asyncio.CancelledError):
+            for fut in self._pending.values():
+                if not fut.done():
+                    fut.set_exception(RuntimeError("GPU worker connection lost"))
+            self._pending.clear()
+
+    async def _call(self, msg_tail, kind: str):
+        if self._writer is None:
+            await self.start()
+        rid = next(self._ids)
+        fut = asyncio.get_running_loop().create_future()
+        self._pending[rid] = fut
+        self._writer.write(frame([kind, rid, *msg_tail]))
+        return await fut
+
+    async def submit(self, query: str, top_k: int, exclude):
+        return await self._call([query, int(top_k), sorted(exclude) if exclude else []], "rec")
+
+    async def reindex(self, corpus_path: str):
+        """-> (corpus_path, n_products) once the worker has swapped in the new catalog."""
+        return await self._call([str(corpus_path)], "corpus")

@@ -1,0 +1,77 @@
+"""Multi-process server: one GPU-owner process + N HTTP front-ends on one port (SO_REUSEPORT).
+
+    python -m instacart_next_order_recommendation_amd.api.serve --workers 6 --port 8000
+
+Env (as the reference's API): MODEL_DIR, CORPUS_PATH, API_KEY; BATCH_MAX_SIZE, BATCH_MAX_WAIT_MS for the worker.
+A single process is still `uvicorn instacart_next_order_recommendation_amd.api.app:app` (reference: uvicorn src.api.main:app).
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import multiprocessing as mp
+import os
+import signal
+import tempfile
+
+
+def _frontend(sock_path: str, host: str, port: int, ready) -> None:
+    os.environ["ICREC_GPU_WORKER_SOCKET"] = sock_path
+    from .app import app
+    from .fastserve import serve
+
+    asyncio.run(serve(app, host, port, reuse_port=True, ready=ready.set))
+
+
+def _worker(sock_path: str, model_dir: str, corpus_path: str, wfd: int) -> None:
+    from .worker import run
+
+    run(sock_path, model_dir, corpus_path, wfd)
+
+
+def start(n_frontends: int, host: str, port: int, model_dir: str, corpus_path: str):
+    """-> (processes, socket path); returns when every process is accepting."""
+    ctx = mp.get_context("spawn")  # the GPU owner must not be a fork of a process with live threads / HIP state
+    sock_path = os.path.join(tempfile.mkdtemp(prefix="icrec_srv_"), "gpu.sock")
+    rfd, wfd = os.pipe()
+    os.set_inheritable(wfd, True)
+    procs = [ctx.Process(target=_worker, args=(sock_path, model_dir, corpus_path, wfd), daemon=True)]
+    procs[0].start()
+    os.close(wfd)
+    if os.read(rfd, 1) != b"1":
+        raise RuntimeError("GPU worker failed to start")
+    os.close(rfd)
+    events = []
+    for _ in range(n_frontends):
+        ev = ctx.Event()
+        p = ctx.Process(target=_frontend, args=(sock_path, host, port, ev), daemon=True)
+        p.start()
+        procs.append(p)
+        events.append(ev)
+    for ev in events:
+        if not ev.wait(120):
+            raise RuntimeError("an HTTP front-end failed to start")
+    return procs, sock_path
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser(description="GPU worker + N HTTP front-ends")
+    ap.add_argument("--workers", type=int, default=4, help="HTTP front-end processes")
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=8000)
+    args = ap.parse_args()
+    model_dir = os.getenv("MODEL_DIR", "models/two_tower_sbert/final")
+    corpus_path = os.getenv("CORPUS_PATH", "processed/p5_mp20_ef0.1/eval_corpus.json")
+    procs, _ = start(args.workers, args.host, args.port, model_dir, corpus_path)
+    print(f"serving on {args.host}:{args.port} with {args.workers} front-ends + 1 GPU worker", flush=True)
+    signal.signal(signal.SIGTERM, lambda *_: (_ for _ in ()).throw(KeyboardInterrupt()))
+    try:
+        for p in procs:
+            p.join()
+    except KeyboardInterrupt:
+        for p in procs:
+            p.terminate()
+
+
+if __name__ == "__main__":
+    main()
