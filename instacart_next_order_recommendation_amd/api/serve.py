@@ -23,24 +23,22 @@ def _frontend(sock_path: str, host: str, port: int, ready) -> None:
     asyncio.run(serve(app, host, port, reuse_port=True, ready=ready.set))
 
 
-def _worker(sock_path: str, model_dir: str, corpus_path: str, wfd: int) -> None:
+def _worker(sock_path: str, model_dir: str, corpus_path: str, ready) -> None:
     from .worker import run
 
-    run(sock_path, model_dir, corpus_path, wfd)
+    run(sock_path, model_dir, corpus_path, ready.set)
 
 
 def start(n_frontends: int, host: str, port: int, model_dir: str, corpus_path: str):
     """-> (processes, socket path); returns when every process is accepting."""
     ctx = mp.get_context("spawn")  # the GPU owner must not be a fork of a process with live threads / HIP state
     sock_path = os.path.join(tempfile.mkdtemp(prefix="icrec_srv_"), "gpu.sock")
-    rfd, wfd = os.pipe()
-    os.set_inheritable(wfd, True)
-    procs = [ctx.Process(target=_worker, args=(sock_path, model_dir, corpus_path, wfd), daemon=True)]
+    wready = ctx.Event()
+    procs = [ctx.Process(target=_worker, args=(sock_path, model_dir, corpus_path, wready), daemon=True)]
     procs[0].start()
-    os.close(wfd)
-    if os.read(rfd, 1) != b"1":
-        raise RuntimeError("GPU worker failed to start")
-    os.close(rfd)
+    while not wready.wait(0.5):  # model load + catalog encode
+        if not procs[0].is_alive():
+            raise RuntimeError("GPU worker failed to start")
     events = []
     for _ in range(n_frontends):
         ev = ctx.Event()

@@ -94,16 +94,15 @@ class GpuWorker:
             writer.close()
 
 
-def run(sock_path: str, model_dir, corpus_path, ready_fd: int | None = None) -> None:
+def run(sock_path: str, model_dir, corpus_path, ready=None) -> None:
     logging.basicConfig(level=logging.INFO, format="%(message)s")
 
     async def main():
         w = GpuWorker(model_dir, corpus_path)
         server = await asyncio.start_unix_server(w.handle, path=sock_path, limit=1 << 26)
         logger.info("GPU worker ready on %s (%d products)", sock_path, len(w.recommender.product_ids))
-        if ready_fd is not None:
-            os.write(ready_fd, b"1")
-            os.close(ready_fd)
+        if ready is not None:
+            ready()
         async with server:
             await server.serve_forever()
 
