@@ -37,8 +37,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None,
                     help="user contexts per GPU per step (default: 1024 on one GPU = BASELINE configs[1]/[2]; "
                          "4096 / N at N > 1 = configs[3]'s 4,096-query batch over the sharded catalog)")
@@ -106,25 +106,41 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
                                f"search {t2 - t1:.2f}s on the same sample"}}
 
 
-def roofline(mode: str, achieved: float, n: int, ms: float, flops: float) -> dict:
-    """Roofline entry for the dominant kernel (the FFN up-projection GEMM, 6 launches per step).
-    `achieved` counts ALGORITHMIC FLOPs (2*T*384*1536) once, whatever the arithmetic."""
+def load_traffic(kernel_key: str):
+    """HBM-side bytes per launch of `kernel_key` from the committed PMC record (profiles/r02_roofline_traffic.json:
+    two rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 rule, WRITE_SIZE as is; written by
+    tools/pmc_traffic_json.py).  (None, note) when the record is missing."""
+    path = ROOT / "profiles" / "r02_roofline_traffic.json"
+    try:
+        rec = json.loads(path.read_text())[kernel_key]
+        return float(rec["traffic_bytes"]), f"{rec['note']} ({path.name})"
+    except Exception:  # noqa: BLE001
+        return None, f"no PMC record for {kernel_key} in {path.name}"
+
+
+def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens: int) -> dict:
+    """Roofline entry for the dominant kernel.  f16x3 mode: the fused FFN kernel (FFN-up + GELU + FFN-down + residual +
+    LayerNorm, 6 launches per step); f32 mode: the FFN up-projection GEMM.  `achieved` counts ALGORITHMIC FLOPs once,
+    whatever the arithmetic (the 3-term split issues 3 MFMAs per product and is priced against 2500/3 TFLOP/s)."""
     if mode == "f32":
+        traffic, note = load_traffic("linear_kernel_gelu")
         return {"kernel": "linear_kernel<128x128, GELU> (FFN up-projection, v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 1.60e9,
-                "traffic_note": "PMC per launch: 2*FETCH_SIZE 795 MB + WRITE_SIZE 806 MB (profiles/r01_pmc_hbm_bytes.txt); algorithmic 1.01 GB",
-                "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops}
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
+                "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
     peak = PEAK_F16_MFMA_TFLOPS / 3.0
-    return {"kernel": "linear_x3_kernel<128x128, GELU+split> (FFN up-projection, 3x v_mfma_f32_32x32x16_f16 per product)",
+    traffic, note = load_traffic("ffn_fused2_kernel")
+    return {"kernel": "ffn_fused2_kernel (FFN-up + erf-GELU + FFN-down + residual + LayerNorm on chip; "
+                      "3x v_mfma_f32_32x32x16_f16 per product, weights streamed L2 -> registers)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "peak_note": "fp32-accurate product = 3 f16 MFMAs, so the algorithm's MFMA roof is 2500/3 TFLOP/s of "
                          "algorithmic FLOPs; against the raw f16 dense peak the fraction is frac_of_f16_dense_peak",
             "frac_of_f16_dense_peak": achieved / PEAK_F16_MFMA_TFLOPS,
-            "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": 1.206e9,
-            "traffic_note": "PMC per launch: 2*FETCH_SIZE 400 MB + WRITE_SIZE 806 MB (profiles/r01_pmc_hbm_bytes_f16x3.txt); "
-                            "algorithmic 1.01 GB (f16 hi/lo planes in, f16 hi/lo planes out)",
-            "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops}
+            "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
+            "algorithmic_bytes": tokens * 384 * (4 + 4 + 4 + 4) + 2 * 2 * 1536 * 384 * 2,
+            "algorithmic_bytes_note": "x planes in (4 B/elt) + fp32 residual in + fp32 x out + planes out, + the layer's "
+                                      "packed W1/W2 fragments once",
+            "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
 
 def main() -> None:
@@ -364,7 +380,15 @@ def main() -> None:
     if rank == 0:
         q_per_step = args.batch * world
         ms_per_step = elapsed / args.steps * 1e3
-        ffn_flops = 2.0 * total_tokens * shape.hidden * shape.intermediate  # algorithmic FLOPs per FFN-up launch
+        import ctypes as C
+
+        t_main, t_tail = C.c_int64(total_tokens), C.c_int64(0)
+        if enc.gemm_mode != "f32":  # the timed launches (slot 1) are the fused FFN kernel over the batch-kernel share of the tokens
+            _native.check(_native.lib().icrec_encode_batch_split(enc._h, total_tokens, C.byref(t_main), C.byref(t_tail)),
+                          "icrec_encode_batch_split")
+        ffn_tokens = int(t_main.value)
+        # algorithmic FLOPs per timed launch: FFN-up only in f32 mode, up + down in the fused kernel
+        ffn_flops = (2.0 if enc.gemm_mode == "f32" else 4.0) * ffn_tokens * shape.hidden * shape.intermediate
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12 if ffn_ms > 0 else 0.0
         out = {
             "metric": "recommend_qps_top20_49k7_catalog" if args.workload == "49k7" else "recommend_qps_top20_10m_catalog",
@@ -404,7 +428,7 @@ def main() -> None:
             "catalog_index_build_note": None if index_build_ms is None else
             f"encode {CATALOG_ROWS} products ({catalog_tokens} tokens, from ids in HBM) + normalise into a DeviceIndex",
             "encode_ms_per_step": enc_ms, "search_ms_per_step": srch_ms, "search_kernel_ms": skern_ms,
-            "roofline": roofline(enc.gemm_mode, achieved, ffn_n, ffn_ms, ffn_flops),
+            "roofline": roofline(enc.gemm_mode, achieved, ffn_n, ffn_ms, ffn_flops, ffn_tokens),
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "49k7":
             out["cpu_baseline"] = cpu_baseline(weights, shape, ids_h, cu_h, catalog, min(args.cpu_sample, args.batch))

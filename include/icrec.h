@@ -117,6 +117,13 @@ ICREC_API int icrec_encode(icrec_encoder* enc,
                  float* out_dev,
                  void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* How icrec_encode will split `total_tokens` (f16x3 mode): main_tokens go through the batch kernels (whole
+ * rounds of one 64-token workgroup per CU; the fused FFN kernel sees exactly this many tokens), tail_tokens — a
+ * remainder of at most 512 tokens — through the small-batch kernels.  Same arithmetic either way; bench.py uses
+ * it to count the FLOPs of the launches it times. */
+ICREC_API int icrec_encode_batch_split(const icrec_encoder* enc, int64_t total_tokens,
+                             int64_t* main_tokens, int64_t* tail_tokens);
+
 /* ------------------------------------------------------------------------- */
 /* Index + search: replaces cos_sim(query_emb, product_embeddings)            */
 /* (serve_recommendations.py:214/:250), scores.argsort(descending=True)       */

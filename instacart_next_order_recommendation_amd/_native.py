@@ -21,7 +21,7 @@ GEMM_MODES = {"f32": GEMM_F32, "f16x3": GEMM_F16X3}
 #: every symbol include/icrec.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "icrec_encoder_weight_count", "icrec_encoder_create", "icrec_encoder_destroy",
-    "icrec_encode_workspace_bytes", "icrec_encode",
+    "icrec_encode_workspace_bytes", "icrec_encode", "icrec_encode_batch_split",
     "icrec_index_create", "icrec_index_create_ex", "icrec_index_destroy", "icrec_index_rows", "icrec_index_storage",
     "icrec_index_export", "icrec_index_dim", "icrec_index_device",
     "icrec_comm_unique_id", "icrec_comm_init", "icrec_comm_destroy", "icrec_comm_rank", "icrec_comm_world",
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         "icrec_encoder_destroy": (C.c_int, [vp]),
         "icrec_encode_workspace_bytes": (sz, [vp, i64, i32]),
         "icrec_encode": (C.c_int, [vp, vp, vp, i32, i64, i32, vp, vp, sz, vp]),
+        "icrec_encode_batch_split": (C.c_int, [vp, i64, C.POINTER(i64), C.POINTER(i64)]),
         "icrec_index_create": (C.c_int, [vp, i64, i32, i64, C.c_int, C.POINTER(vp)]),
         "icrec_index_create_ex": (C.c_int, [vp, i64, i32, i64, C.c_int, i32, C.POINTER(vp)]),
         "icrec_index_storage": (i32, [vp]),

@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
     constexpr int SM = (STAGED && 32 * LN_LD * 4 > XRing<TTW>::BYTES) ? 32 * LN_LD * 4 : XRing<TTW>::BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM];
     const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-    const int mt = blockIdx.x / n_blocks_n, nb = blockIdx.x % n_blocks_n;
+    // the n_blocks_n workgroups that read the same token rows get consecutive logical ids = the same XCD = one L2
+    // (PMC: without the remap the QKV launch fetched its activations three times, 930 MB instead of ~330 MB)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
     const int64_t m0 = (int64_t)mt * (32 * TTW);
     const int nt0 = (nb * 4 + q) * NTW;
     f32x16 acc[NTW][TTW];
@@ -1379,6 +1382,29 @@ size_t icrec_encode_workspace_bytes(const icrec_encoder* h, int64_t total_tokens
     return enc_ws(e->cfg, total_tokens).total;
 }
 
+// How icrec_encode splits a batch of T tokens (f16x3 mode): [0, main) through the batch kernels in whole rounds of
+// one 64-token workgroup per CU, [main, T) — a short remainder, or everything for small batches — through the
+// small-batch kernels.
+static void batch_split(const Encoder* e, int T, int* t_main, int* t_tail) {
+    const int round_tokens = 64 * e->n_cu;
+    *t_main = T;
+    *t_tail = 0;
+    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= X3_SMALL_M) {
+        *t_tail = T % round_tokens;
+        *t_main = T - *t_tail;
+    }
+}
+
+int icrec_encode_batch_split(const icrec_encoder* h, int64_t total_tokens, int64_t* main_tokens, int64_t* tail_tokens) {
+    const Encoder* e = reinterpret_cast<const Encoder*>(h);
+    ICREC_REQUIRE(e && main_tokens && tail_tokens && total_tokens >= 1 && total_tokens < (1ll << 31), "icrec_encode_batch_split: bad argument");
+    int m, t;
+    batch_split(e, (int)total_tokens, &m, &t);
+    *main_tokens = m;
+    *tail_tokens = t;
+    return ICREC_OK;
+}
+
 int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev, int32_t n_seqs, int64_t T64,
                  int32_t max_seqlen, float* out_dev, void* ws, size_t ws_bytes, void* stream) {
     Encoder* e = reinterpret_cast<Encoder*>(h);
@@ -1405,12 +1431,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const int rows_grid = (T + 3) / 4;
     const bool x3 = c.gemm_mode == ICREC_GEMM_F16X3;
     // whole rounds of the fused FFN kernel (one 64-token workgroup per CU) + a short remainder, see the layer loop
-    const int round_tokens = 64 * e->n_cu;
-    int T_main = T, T_tail = 0;
-    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= X3_SMALL_M) {
-        T_tail = T % round_tokens;
-        T_main = T - T_tail;
-    }
+    int T_main, T_tail;
+    batch_split(e, T, &T_main, &T_tail);
     const char* fuse_env = getenv("ICREC_FUSE");  // ICREC_FUSE=0: A/B switch to the unfused kernels (read per call: tests flip it)
     const bool fuse = !(fuse_env && fuse_env[0] == '0');
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
