@@ -136,6 +136,30 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) { return x * 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// erf-GELU of the f16x3 engine, times the activation plane scale (16): one polynomial, one v_exp_f32, 16 VALU.
+//   gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2),     erfc(t / sqrt 2) = 2^Q10(min(t, 5.75))
+// (x >= 0: x - 0.5 x erfc = 0.5 x (1 + erf);  x < 0: 0.5 x erfc(|z|) = 0.5 x (1 + erf(z)).)  Only ABSOLUTE accuracy of
+// erfc matters here - it multiplies |x| and is added to a term of the size of x - so the separate small-|x| branch of
+// erf_fast (kept for relative accuracy of erf itself) is not needed.  Q10: Chebyshev fit of log2(erfc(t / sqrt 2)) on
+// [0, 5.75] (tools/fit_erf.py --gelu); in emulated fp32 fma arithmetic over 440k points: max |error| 2.4e-7 (half an
+// ulp at x = 4.3), relative error <= 1.05e-6 wherever |gelu| > 1e-3.
+__device__ __forceinline__ float gelu16_wt(float x) {
+    const float t = fminf(fabsf(x), 5.75f);
+    float q = -1.428101063e-08f;
+    q = fmaf(q, t, 4.683960178e-07f);
+    q = fmaf(q, t, -6.560040814e-06f);
+    q = fmaf(q, t, 4.923233760e-05f);
+    q = fmaf(q, t, -1.793856253e-04f);
+    q = fmaf(q, t, -2.251562182e-04f);
+    q = fmaf(q, t, 7.249582803e-03f);
+    q = fmaf(q, t, -5.267105742e-02f);
+    q = fmaf(q, t, -4.591336602e-01f);
+    q = fmaf(q, t, -1.151116827e+00f);
+    q = fmaf(q, t, 2.960897358e-07f);
+    const float e = __builtin_amdgcn_exp2f(q);
+    return fmaf(fabsf(x) * -8.0f, e, fmaxf(x * 16.0f, 0.0f));
+}
+
 template <class Cfg, bool GELU>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __restrict__ A, int M, int K,
                                                                  const float* __restrict__ W, int N,
@@ -245,13 +269,11 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                     for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
                     if (EPI == 1) {
                         half4 hi, lo;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            _Float16 a, c;
-                            split_act(gelu_erf_fast(v[j]), a, c);
-                            hi[j] = a;
-                            lo[j] = c;
-                        }
+                        half2w a, b, c, d;
+                        split_pair_prescaled(gelu16_wt(v[0]), gelu16_wt(v[1]), a, b);
+                        split_pair_prescaled(gelu16_wt(v[2]), gelu16_wt(v[3]), c, d);
+                        hi = half4{a[0], a[1], c[0], c[1]};
+                        lo = half4{b[0], b[1], d[0], d[1]};
                         *reinterpret_cast<half4*>(oh + tok * N + feat) = hi;
                         *reinterpret_cast<half4*>(ol + tok * N + feat) = lo;
                     } else {
@@ -390,13 +412,7 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
                 if (g < T) {
                     const f32x4 y = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
                     half4 hi, lo;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        _Float16 a, d;
-                        split_act(y[j], a, d);
-                        hi[j] = a;
-                        lo[j] = d;
-                    }
+                    split_act4(y, hi, lo);
                     *reinterpret_cast<f32x4*>(x + g * 384 + c * 4) = y;
                     *reinterpret_cast<half4*>(xh + g * 384 + c * 4) = hi;
                     *reinterpret_cast<half4*>(xl + g * 384 + c * 4) = lo;
@@ -464,13 +480,8 @@ __global__ __launch_bounds__(256) void add_ln_wt_kernel(const float* __restrict_
             f32x4 y;
             half4 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                y[j] = fmaf(v[i][g][j] * rstd, gm[j], bt[j]);
-                _Float16 p, c;
-                split_act(y[j], p, c);
-                hi[j] = p;
-                lo[j] = c;
-            }
+            for (int j = 0; j < 4; ++j) y[j] = fmaf(v[i][g][j] * rstd, gm[j], bt[j]);
+            split_act4(y, hi, lo);
             if (ok) {
                 *reinterpret_cast<f32x4*>(x + tok * 384 + feat) = y;
                 *reinterpret_cast<half4*>(xh + tok * 384 + feat) = hi;
@@ -653,14 +664,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
                     constexpr int dummy_ = 0;
                     (void)dummy_;
                     const int u = ks - ks / 3;
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int n = 2 * u + jj, gi = n >> 2, j = n & 3, g = gi >> 1, tt = gi & 1;
-                        _Float16 a, d;
-                        const float pre = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
-                        split_act((VAR & 1) ? pre : gelu_erf_fast(pre), a, d);
-                        ghi[j] = a;
-                        glo[j] = d;
+                    {
+                        const int n = 2 * u, gi = n >> 2, j = n & 3, g = gi >> 1, tt = gi & 1;  // elements j, j + 1 of group gi
+                        const float p0 = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
+                        const float p1 = fmaf(Sp[0][tt][4 * g + j + 1], WT_UNSCALE, biasp[g][j + 1]);
+                        half2w a, d;
+                        split_pair_prescaled((VAR & 1) ? p0 : gelu16_wt(p0), (VAR & 1) ? p1 : gelu16_wt(p1), a, d);
+                        ghi[j] = a[0];
+                        ghi[j + 1] = a[1];
+                        glo[j] = d[0];
+                        glo[j + 1] = d[1];
                     }
                     if (u & 1) {
                         const int gi = u >> 1, g = gi >> 1, tt = gi & 1;

@@ -41,7 +41,34 @@ __device__ __forceinline__ void split_scaled(float x, float scale, _Float16& hi,
     hi = (_Float16)s;
     lo = (_Float16)(s - (float)hi);
 }
-__device__ __forceinline__ void split_act(float x, _Float16& hi, _Float16& lo) { split_scaled(x, WT_SA, hi, lo); }
+// Activations are split on the fly (LayerNorm / GELU / attention epilogues), so their split is the cheap form:
+//   s = 16 x;  hi = s with the low 13 mantissa bits cleared (exactly an 11-bit value, i.e. an f16 for normal
+//   magnitudes);  lo = s - hi (exact in fp32);  both converted with v_cvt_pkrtz_f16_f32, two elements per instruction
+// = 3 VALU per element instead of 6.  hi + lo still carries s to 2^-21 relative (lo is rounded toward zero: one ulp of
+// an 11-bit residual); below the f16 normal range (|x| < 3.8e-6) the absolute error is < 2^-24 / 16; beyond it
+// (|x| > 4094) the conversion saturates at +-65504 instead of overflowing.  Every producer of activation planes uses
+// this one function, so a tensor's planes are the same bits whichever kernel wrote them.
+typedef _Float16 half2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_prescaled(float s0, float s1, half2w& hi, half2w& lo) {
+    const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+    const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+    hi = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    lo = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(s0 - h0, s1 - h1));
+}
+// four consecutive elements -> the 8-byte hi and lo pieces the epilogues store
+__device__ __forceinline__ void split_act4(const f32x4& v, half4& hi, half4& lo) {
+    half2w a, b, c, d;
+    split_pair_prescaled(v[0] * WT_SA, v[1] * WT_SA, a, b);
+    split_pair_prescaled(v[2] * WT_SA, v[3] * WT_SA, c, d);
+    hi = half4{a[0], a[1], c[0], c[1]};
+    lo = half4{b[0], b[1], d[0], d[1]};
+}
+__device__ __forceinline__ void split_act(float x, _Float16& hi, _Float16& lo) {
+    half2w a, b;
+    split_pair_prescaled(x * WT_SA, 0.0f, a, b);
+    hi = a[0];
+    lo = b[0];
+}
 
 // ---------------------------------------------------------------- packed weights
 // W [N, K] fp32 row-major -> fragment order: fragment (nt, ks, plane) = 512 halfs at ((nt * K/16 + ks) * 2 + plane) * 512,

@@ -1,5 +1,7 @@
-"""Fit and check the coefficients of erf_fast (csrc/encoder.hip): Chebyshev fits of erf(x)/x in x^2 on [0, 0.921875]
+"""Fit and check the coefficients of erf_fast and (with --gelu) gelu16_wt (csrc/encoder.hip): Chebyshev fits of erf(x)/x in x^2 on [0, 0.921875]
 and of log2(erfc(t)) on [0.921875, 4], evaluated in emulated float32 fma arithmetic against scipy over 620k points."""
+import sys
+
 import numpy as np
 from scipy.special import erf
 from numpy.polynomial import chebyshev as C, polynomial as Pn
@@ -34,3 +36,28 @@ nz = np.abs(want) > 0
 print("max rel err", (err[nz]/np.abs(want[nz])).max(), "ulps", (err[nz]/np.abs(want[nz])).max()/2**-24)
 print("A:", ", ".join("%.9ef" % v for v in cA))
 print("B:", ", ".join("%.9ef" % v for v in cB))
+
+
+def fit_gelu():
+    """gelu16_wt: gelu(x) = max(x,0) - 0.5|x| * 2^Q(min(|x|, 5.75)), Q = Chebyshev fit of log2(erfc(t/sqrt 2)) on [0, 5.75]."""
+    from mpmath import sqrt
+    CAP = 5.75
+    t = nodes(0, CAP, 800)
+    y = np.array([float(log(erfc(mp.mpf(v)/sqrt(2)))/log(2)) for v in t])
+    xs = np.concatenate([np.linspace(-8, 8, 400001), np.logspace(-8, 0, 20001), -np.logspace(-8, 0, 20001)]).astype(f32)
+    want = 0.5*xs.astype(np.float64)*(1+erf(xs.astype(np.float64)/np.sqrt(2)))
+    for deg in (9, 10, 11):
+        cQ = C.Chebyshev.fit(t, y, deg, domain=[0, CAP]).convert(kind=Pn.Polynomial).coef
+        tt = np.minimum(np.abs(xs), f32(CAP)).astype(f32)
+        r = np.full_like(xs, f32(cQ[-1]))
+        for k in cQ[-2::-1]: r = fma(r, tt, f32(k))
+        e = np.exp2(r.astype(np.float64)).astype(f32)
+        g = fma((f32(-0.5)*np.abs(xs)).astype(f32), e, np.maximum(xs, f32(0)))
+        err = np.abs(g.astype(np.float64) - want)
+        big = np.abs(want) > 1e-3
+        print(deg, "max abs err %.3e at x=%.4f" % (err.max(), xs[err.argmax()]), " max rel err where |gelu|>1e-3: %.3e" % (err[big]/np.abs(want[big])).max())
+        print("  Q:", ", ".join("%.9ef" % v for v in cQ))
+
+
+if "--gelu" in sys.argv:
+    fit_gelu()
