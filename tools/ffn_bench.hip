@@ -103,13 +103,28 @@ int main(int argc, char** argv) {
         dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 30});
         dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 30});
         reinit();
-        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
+        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3, QkvOut{});
         hipDeviceSynchronize();
         dump("qkv wave0", nb * 3, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
         hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
         hipDeviceSynchronize();
         dump("attn-out+LN wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
         reinit();
+        {   // attention, long bucket: 512 sequences of 200 tokens
+            const int nseq = 512, Ls = 200;
+            std::vector<int> cuh(nseq + 1);
+            for (int i = 0; i <= nseq; ++i) cuh[i] = i * Ls;
+            int* cud; hipMalloc(&cud, (nseq + 1) * 4); hipMemcpy(cud, cuh.data(), (nseq + 1) * 4, hipMemcpyHostToDevice);
+            fill_float<<<1024, 256>>>(qkv, (size_t)nseq * Ls * 3 * H, 21, 2.0f);
+            const float sl2e = (1.0f / sqrtf(32.0f)) * 1.44269504088896340736f;
+            for (int rep = 0; rep < 2; ++rep)
+                hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl);
+            hipDeviceSynchronize();
+            dump("attention long (L=200) wave0", nseq * 12, 0, {0, 1, 2, 3, 4, 5});
+            timeit("attention_x3<8,8> 512 seq x 200 tok", [&] {
+                hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl);
+            }, 4.0 * nseq * 12 * Ls * Ls * 32);
+        }
         return 0;
     }
 #endif
@@ -128,7 +143,7 @@ int main(int argc, char** argv) {
         }
         reinit();
         timeit("qkv wt_linear<3,2,2,0> N=1152", [&] {
-            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
+            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3, QkvOut{});
         }, 2.0 * T * H * 3 * H);
         timeit("attn-out + LN wt_linear_ln<2>", [&] {
             hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
