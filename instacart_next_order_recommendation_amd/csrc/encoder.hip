@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                             split_act4(v, hi, lo);
                             _Float16* const row_h = qo.vt + (int64_t)feat * qo.Tpad;  // feat = head*32 + dim
                             const int p0 = qo.pos[tok0];
-                            const bool whole = tok0 + 3 < T && (p0 & 3) == 0 && qo.pos[tok0 + 3] == p0 + 3;
+                            const bool whole = tok0 + 3 < T && p0 >= 0 && (p0 & 3) == 0 && qo.pos[tok0 + 3] == p0 + 3;
                             if (whole) {  // the same sequence, 4-aligned: slots are consecutive
                                 *reinterpret_cast<half4*>(row_h + vt_slot(p0)) = hi;
                                 *reinterpret_cast<half4*>(row_h + plane_vt + vt_slot(p0)) = lo;
                             } else {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i)
-                                    if (tok0 + i < T) {
+                                    if (tok0 + i < T && qo.pos[tok0 + i] >= 0) {
                                         const int s_ = vt_slot(qo.pos[tok0 + i]);
                                         row_h[s_] = hi[i];
                                         row_h[plane_vt + s_] = lo[i];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                             const int64_t at = ((int64_t)head * qo.T + tok) * 32 + dim;
                             *reinterpret_cast<half4*>(dst + at) = hi;
                             *reinterpret_cast<half4*>(dst + (int64_t)qo.heads * qo.T * 32 + at) = lo;
-                        } else {
+                        } else if (qo.pos[tok] >= 0) {
                             const int s_ = vt_slot(qo.pos[tok]);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -1449,6 +1449,10 @@ __global__ __launch_bounds__(256) void pad_pos_kernel(const int32_t* __restrict_
                                                       int32_t* __restrict__ pos) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
+    if (t >= cu[n_seqs]) {  // a row outside every sequence (hipGraph replays run a fixed row count): it owns no V^T slot —
+        pos[t] = -1;        // its values (possibly garbage: attention never wrote its context) must not land in a real
+        return;             // sequence's padding
+    }
     const int s = find_seq(cu, n_seqs, t);
     pos[t] = padcu[s] + t - cu[s];
 }

@@ -193,3 +193,32 @@ def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch):
     monkeypatch.delenv("ICREC_FUSE")
     np.testing.assert_array_equal(fused, unfused)
     enc.close()
+
+
+@pytest.mark.parametrize("shape", ["short_batch", "long_batch", "single"])
+def test_workspace_contents_never_leak_into_results(minilm_weights, shape):
+    """The caller-owned workspace may hold anything (here: NaN bit patterns everywhere) — every byte a kernel reads
+    must have been written by the same icrec_encode call.  Poisoned and zeroed workspaces give identical bits."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+
+    enc = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    if shape == "short_batch":      # catalog-like: 700 short sequences, batch kernels, short attention bucket only
+        ids, cu = syn.synthetic_token_batch(700, seed=3, mean_len=25, std_len=6, lo=8, hi=40)
+    elif shape == "long_batch":     # mixed lengths incl. the long bucket and a remainder through the small kernels
+        ids, cu = syn.synthetic_token_batch(130, seed=4, mean_len=128, std_len=60, lo=1, hi=256)
+    else:
+        ids, cu = syn.synthetic_token_batch(1, seed=5, mean_len=70, std_len=1, lo=69, hi=71)
+    args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), int(np.diff(cu).max()))
+    enc.encode_packed(*args)                      # sizes the workspace
+    ws = enc._ws_slots[0]
+    out = []
+    for fill in (0xFF, 0x00, 0x7F):
+        ws.fill_(fill)
+        out.append(enc.encode_packed(*args).cpu().numpy())
+        assert np.isfinite(out[-1]).all(), f"workspace byte 0x{fill:02X} leaked into the embeddings"
+    np.testing.assert_array_equal(out[0], out[1])
+    np.testing.assert_array_equal(out[0], out[2])
+    enc.close()
