@@ -194,21 +194,27 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
     }
 }
 
-// Where the QKV projection's epilogue (EPI 2) puts its results for attention_wt_kernel — f16 hi/lo planes, head-major:
-//   q, k   [plane][head][T][32]        a (sequence, head) slice is one contiguous run of 64-byte rows
-//   vt     [plane][head][32][Tpad]     V transposed (keys contiguous): every sequence starts at a multiple of 32 padded
-//          positions (`pos` maps token -> padded position), and inside each group of 16 positions key k sits at
-//          8((k>>2)&1) + (k&3) + 4(k>>3): the order in which the P.V MFMA consumes the keys of an accumulator
-//          register group, so a B fragment is 16 contiguous bytes
+// Where the QKV projection's epilogue (EPI 2) puts its results for attention_wt_kernel: f16 hi/lo planes in FRAGMENT
+// order over the batch's padded layout (every sequence starts at a multiple of 32 padded positions; `pos` maps token ->
+// padded position, -1 for a row outside every sequence).  The 1 KB a wave loads for one MFMA operand is contiguous,
+// lane l's 16 bytes at 16 l:
+//   q, k   [plane][head][tile = p >> 5][ks = d >> 4][h = (d >> 3) & 1][r = p & 31][8]   A/B fragment of 32 rows x 16 dims
+//   vt     [plane][head][group = p >> 4][h][dim][8]   V transposed, 16 keys per fragment; key k = p & 15 sits at
+//          h = (k >> 2) & 1, j = (k & 3) + 4 (k >> 3): the order in which the P.V MFMA consumes the keys of an
+//          accumulator register group
+// Tpad = padded positions of the batch (a multiple of 32).
 struct QkvOut {
     _Float16 *q, *k, *vt;
     const int32_t* pos;
     int64_t T, Tpad;
     int heads;
 };
-__device__ __forceinline__ int vt_slot(int p) {  // padded position -> storage position
+__device__ __forceinline__ int64_t qk_off(int hd, int64_t Tpad, int p, int d) {  // halfs inside one plane
+    return (((((int64_t)hd * (Tpad >> 5) + (p >> 5)) * 2 + (d >> 4)) * 2 + ((d >> 3) & 1)) * 32 + (p & 31)) * 8 + (d & 7);
+}
+__device__ __forceinline__ int64_t vt_off(int hd, int64_t Tpad, int p, int d) {
     const int k = p & 15;
-    return (p & ~15) + 8 * ((k >> 2) & 1) + (k & 3) + 4 * (k >> 3);
+    return ((((int64_t)hd * (Tpad >> 4) + (p >> 4)) * 2 + ((k >> 2) & 1)) * 32 + d) * 8 + (k & 3) + 4 * (k >> 3);
 }
 
 constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 16-B accesses of consecutive tokens hit distinct banks)
@@ -259,25 +265,26 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                 }
             __syncthreads();
             if constexpr (EPI == 2) {
-                const int64_t plane_qk = (int64_t)qo.heads * qo.T * 32, plane_vt = (int64_t)qo.heads * 32 * qo.Tpad;
-                if (nb < 2) {  // Q or K: (head, token, 4-dim chunk) order -> a wave writes 8 tokens x 64 B = 512 contiguous bytes per plane
+                const int64_t plane = (int64_t)qo.heads * 32 * qo.Tpad;  // halfs per plane (q, k and vt alike)
+                if (nb < 2) {  // Q or K: (head, token, 4-dim chunk) order -> 8 consecutive tokens fill 128 contiguous bytes of each fragment half
                     _Float16* const dst = nb == 0 ? qo.q : qo.k;
 #pragma unroll
                     for (int k = 0; k < 12; ++k) {
                         const int f = threadIdx.x + 256 * k, head = f >> 8, row = (f >> 3) & 31, c8 = f & 7;
                         const int64_t tok = m0 + tt * 32 + row;
-                        if (tok < T) {
+                        const int p = tok < T ? qo.pos[tok] : -1;
+                        if (p >= 0) {
                             half4 hi, lo;
                             split_act4(*reinterpret_cast<const f32x4*>(stage + row * LN_LD + head * 32 + c8 * 4), hi, lo);
-                            const int64_t at = ((int64_t)head * qo.T + tok) * 32 + c8 * 4;
+                            const int64_t at = qk_off(head, qo.Tpad, p, c8 * 4);
                             *reinterpret_cast<half4*>(dst + at) = hi;
-                            *reinterpret_cast<half4*>(dst + plane_qk + at) = lo;
+                            *reinterpret_cast<half4*>(dst + plane + at) = lo;
                         }
                     }
-                } else {  // V, transposed: (feature, 4 consecutive tokens) per thread -> 8 bytes of one V^T row
+                } else {  // V, transposed: (feature, 4 consecutive tokens) per thread -> 8 bytes of one fragment row
 #pragma unroll
                     for (int k = 0; k < 12; ++k) {
-                        const int f = threadIdx.x + 256 * k, feat = f >> 3, tg = f & 7;
+                        const int f = threadIdx.x + 256 * k, feat = f >> 3, tg = f & 7, head = feat >> 5, dim = feat & 31;
                         const int64_t tok0 = m0 + tt * 32 + tg * 4;
                         if (tok0 < T) {
                             f32x4 v;
@@ -285,19 +292,19 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                             for (int i = 0; i < 4; ++i) v[i] = stage[(tg * 4 + i) * LN_LD + feat];
                             half4 hi, lo;
                             split_act4(v, hi, lo);
-                            _Float16* const row_h = qo.vt + (int64_t)feat * qo.Tpad;  // feat = head*32 + dim
                             const int p0 = qo.pos[tok0];
                             const bool whole = tok0 + 3 < T && p0 >= 0 && (p0 & 3) == 0 && qo.pos[tok0 + 3] == p0 + 3;
-                            if (whole) {  // the same sequence, 4-aligned: slots are consecutive
-                                *reinterpret_cast<half4*>(row_h + vt_slot(p0)) = hi;
-                                *reinterpret_cast<half4*>(row_h + plane_vt + vt_slot(p0)) = lo;
+                            if (whole) {  // the same sequence, 4-aligned: the four keys are consecutive in the fragment
+                                const int64_t at = vt_off(head, qo.Tpad, p0, dim);
+                                *reinterpret_cast<half4*>(qo.vt + at) = hi;
+                                *reinterpret_cast<half4*>(qo.vt + plane + at) = lo;
                             } else {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i)
                                     if (tok0 + i < T && qo.pos[tok0 + i] >= 0) {
-                                        const int s_ = vt_slot(qo.pos[tok0 + i]);
-                                        row_h[s_] = hi[i];
-                                        row_h[plane_vt + s_] = lo[i];
+                                        const int64_t at = vt_off(head, qo.Tpad, qo.pos[tok0 + i], dim);
+                                        qo.vt[at] = hi[i];
+                                        qo.vt[plane + at] = lo[i];
                                     }
                             }
                         }
@@ -332,20 +339,24 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
                     if (EPI == 2) {  // QKV planes, lane-per-token form (small batches only)
-                        half4 hi, lo;
-                        split_act4(v, hi, lo);
-                        const int part = feat / 384, fi = feat - part * 384, head = fi >> 5, dim = fi & 31;
-                        if (part < 2) {
-                            _Float16* const dst = part == 0 ? qo.q : qo.k;
-                            const int64_t at = ((int64_t)head * qo.T + tok) * 32 + dim;
-                            *reinterpret_cast<half4*>(dst + at) = hi;
-                            *reinterpret_cast<half4*>(dst + (int64_t)qo.heads * qo.T * 32 + at) = lo;
-                        } else if (qo.pos[tok] >= 0) {
-                            const int s_ = vt_slot(qo.pos[tok]);
+                        const int p = qo.pos[tok];
+                        if (p >= 0) {
+                            half4 hi, lo;
+                            split_act4(v, hi, lo);
+                            const int part = feat / 384, fi = feat - part * 384, head = fi >> 5, dim = fi & 31;
+                            const int64_t plane = (int64_t)qo.heads * 32 * qo.Tpad;
+                            if (part < 2) {
+                                _Float16* const dst = part == 0 ? qo.q : qo.k;
+                                const int64_t at = qk_off(head, qo.Tpad, p, dim);
+                                *reinterpret_cast<half4*>(dst + at) = hi;
+                                *reinterpret_cast<half4*>(dst + plane + at) = lo;
+                            } else {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                qo.vt[(int64_t)(fi + j) * qo.Tpad + s_] = hi[j];
-                                qo.vt[(int64_t)qo.heads * 32 * qo.Tpad + (int64_t)(fi + j) * qo.Tpad + s_] = lo[j];
+                                for (int j = 0; j < 4; ++j) {
+                                    const int64_t at = vt_off(head, qo.Tpad, p, dim + j);
+                                    qo.vt[at] = hi[j];
+                                    qo.vt[plane + at] = lo[j];
+                                }
                             }
                         }
                     } else if (EPI == 1) {
@@ -1292,33 +1303,30 @@ __global__ __launch_bounds__(256, NKT == 8 ? 2 : 4) void attention_wt_kernel(Qkv
     if (NKT == 2 ? nkt > 2 : nkt <= 2) return;  // the other bucket's sequence
     const int qb = (p0 - pbase) >> 5;
     if (qb >= nkt) return;
-    const int64_t plane_qk = (int64_t)qo.heads * qo.T * 32, plane_vt = (int64_t)qo.heads * 32 * qo.Tpad;
+    const int64_t plane = (int64_t)qo.heads * 32 * qo.Tpad;  // halfs per plane
+    const unsigned lo8 = lane * 8;                            // lane = (h << 5) | r: this lane's 16 bytes of a fragment
 
-    half8 qh[2], ql[2];
+    half8 qh[2], ql[2];  // rows past the sequence end are padding (never stored, they only feed their own lanes)
     {
-        int qr = qb * 32 + r;
-        qr = qr < L ? qr : L - 1;
-        const _Float16* qp = qo.q + ((int64_t)hd * qo.T + t0 + qr) * 32 + 8 * h;
+        const _Float16* qp = qo.q + ((int64_t)hd * (qo.Tpad >> 5) + (p0 >> 5)) * 2048 + lo8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qh[ks] = *reinterpret_cast<const half8*>(qp + 16 * ks);
-            ql[ks] = *reinterpret_cast<const half8*>(qp + plane_qk + 16 * ks);
+            qh[ks] = *reinterpret_cast<const half8*>(qp + ks * 512);
+            ql[ks] = *reinterpret_cast<const half8*>(qp + plane + ks * 512);
         }
     }
-    const _Float16* const kbase = qo.k + ((int64_t)hd * qo.T + t0) * 32 + 8 * h;
+    const _Float16* const kbase = qo.k + ((int64_t)hd * (qo.Tpad >> 5) + (pbase >> 5)) * 2048 + lo8;
     f32x16 sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
         if (kt < nkt) {
-            int key = kt * 32 + r;
-            key = key < L ? key : L - 1;  // keys past the end: a valid row, masked below
-            const _Float16* kp = kbase + (int64_t)key * 32;
+            const _Float16* kp = kbase + kt * 2048;  // keys past the end of the last tile: padding, masked below
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const half8 kh = *reinterpret_cast<const half8*>(kp + 16 * ks);
-                const half8 kl = *reinterpret_cast<const half8*>(kp + plane_qk + 16 * ks);
+                const half8 kh = *reinterpret_cast<const half8*>(kp + ks * 512);
+                const half8 kl = *reinterpret_cast<const half8*>(kp + plane + ks * 512);
                 sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sc[kt], 0, 0, 0);
                 sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc[kt], 0, 0, 0);
                 sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc[kt], 0, 0, 0);
@@ -1359,7 +1367,7 @@ __global__ __launch_bounds__(256, NKT == 8 ? 2 : 4) void attention_wt_kernel(Qkv
     }
     if (h == 0) Ls[wave][r] = lsum;
 
-    const _Float16* const vbase = qo.vt + ((int64_t)hd * 32 + r) * qo.Tpad + pbase + 8 * h;
+    const _Float16* const vbase = qo.vt + ((int64_t)hd * (qo.Tpad >> 4) + (pbase >> 4)) * 512 + lo8;
     f32x16 o;
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.0f;
@@ -1368,8 +1376,8 @@ __global__ __launch_bounds__(256, NKT == 8 ? 2 : 4) void attention_wt_kernel(Qkv
         if (kt < nkt) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const half8 vh = *reinterpret_cast<const half8*>(vbase + kt * 32 + 16 * ks);
-                const half8 vl = *reinterpret_cast<const half8*>(vbase + plane_vt + kt * 32 + 16 * ks);
+                const half8 vh = *reinterpret_cast<const half8*>(vbase + (kt * 2 + ks) * 512);
+                const half8 vl = *reinterpret_cast<const half8*>(vbase + plane + (kt * 2 + ks) * 512);
                 half8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
@@ -1438,11 +1446,16 @@ __global__ __launch_bounds__(1024) void pad_scan_kernel(const int32_t* __restric
 // hold finite values (they meet p = 0).  One workgroup per sequence zeroes them in all 2 x 384 rows.
 __global__ __launch_bounds__(256) void vt_zero_pad_kernel(const int32_t* __restrict__ cu,
                                                           const int32_t* __restrict__ padcu, _Float16* __restrict__ vt,
-                                                          int64_t Tpad, int rows) {
+                                                          int64_t Tpad, int heads) {
     const int s = blockIdx.x, L = cu[s + 1] - cu[s], pb = padcu[s];
     const int end = (L + 31) & ~31;
-    for (int row = threadIdx.x; row < rows; row += 256)
-        for (int p = L; p < end; ++p) vt[(int64_t)row * Tpad + vt_slot(pb + p)] = (_Float16)0.0f;
+    const int64_t plane = (int64_t)heads * 32 * Tpad;
+    for (int row = threadIdx.x; row < heads * 32; row += 256)
+        for (int p = L; p < end; ++p) {
+            const int64_t at = vt_off(row >> 5, Tpad, pb + p, row & 31);
+            vt[at] = (_Float16)0.0f;
+            vt[plane + at] = (_Float16)0.0f;
+        }
 }
 __global__ __launch_bounds__(256) void pad_pos_kernel(const int32_t* __restrict__ cu,
                                                       const int32_t* __restrict__ padcu, int n_seqs, int T,
@@ -1538,8 +1551,8 @@ static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T, int64_t n_seqs) {
     w.xs = o;  o += al((size_t)T * c.hidden * 4);        // x as f16 hi/lo planes (F16X3)
     w.Tpad = (T + 31 * n_seqs + 31) & ~(int64_t)31;       // every sequence padded to a multiple of 32 keys, at most
     w.qkv = o;
-    w.q = o;     o += al((size_t)T * c.hidden * 4);       // two f16 planes
-    w.k = o;     o += al((size_t)T * c.hidden * 4);
+    w.q = o;     o += al((size_t)w.Tpad * c.hidden * 4);  // two f16 planes over the padded layout
+    w.k = o;     o += al((size_t)w.Tpad * c.hidden * 4);
     w.vt = o;    o += al((size_t)w.Tpad * c.hidden * 4);
     w.pos = o;   o += al((size_t)T * 4);
     w.padcu = o; o += al((size_t)(n_seqs + 1) * 4);
@@ -1775,7 +1788,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
         qo.pos = pos;
         hipLaunchKernelGGL(pad_scan_kernel, dim3(1), dim3(1024), 0, st, cu_dev, n_seqs, padcu);
         hipLaunchKernelGGL(pad_pos_kernel, dim3((T + 255) / 256), dim3(256), 0, st, cu_dev, padcu, n_seqs, T, pos);
-        hipLaunchKernelGGL(vt_zero_pad_kernel, dim3(n_seqs), dim3(256), 0, st, cu_dev, padcu, qo.vt, w.Tpad, 2 * c.hidden);
+        hipLaunchKernelGGL(vt_zero_pad_kernel, dim3(n_seqs), dim3(256), 0, st, cu_dev, padcu, qo.vt, w.Tpad, c.heads);
     }
     if (x3)
         hipLaunchKernelGGL((embed_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T,
@@ -1790,9 +1803,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // CU, a short remainder [T_main, T) through the small-batch kernels (same arithmetic, same bits) instead
             // of costing every batch kernel an extra, almost empty round.
             auto qkv_stage = [&](int r0, int Tn) {
-                QkvOut o = qo;  // token indices inside the launch are relative to r0
-                o.q += (size_t)r0 * DH;
-                o.k += (size_t)r0 * DH;
+                QkvOut o = qo;  // token indices inside the launch are relative to r0; `pos` holds absolute padded positions
                 o.pos += r0;
                 launch_wt_linear<2>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv, nullptr,
                                     nullptr, nullptr, st, o);
