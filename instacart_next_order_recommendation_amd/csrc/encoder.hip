@@ -194,29 +194,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
     }
 }
 
-// Where the QKV projection's epilogue (EPI 2) puts its results for attention_wt_kernel: f16 hi/lo planes in FRAGMENT
-// order over the batch's padded layout (every sequence starts at a multiple of 32 padded positions; `pos` maps token ->
-// padded position, -1 for a row outside every sequence).  The 1 KB a wave loads for one MFMA operand is contiguous,
-// lane l's 16 bytes at 16 l:
-//   q, k   [plane][head][tile = p >> 5][ks = d >> 4][h = (d >> 3) & 1][r = p & 31][8]   A/B fragment of 32 rows x 16 dims
-//   vt     [plane][head][group = p >> 4][h][dim][8]   V transposed, 16 keys per fragment; key k = p & 15 sits at
-//          h = (k >> 2) & 1, j = (k & 3) + 4 (k >> 3): the order in which the P.V MFMA consumes the keys of an
-//          accumulator register group
-// Tpad = padded positions of the batch (a multiple of 32).
-struct QkvOut {
-    _Float16 *q, *k, *vt;
-    const int32_t* pos;
-    int64_t T, Tpad;
-    int heads;
-};
-__device__ __forceinline__ int64_t qk_off(int hd, int64_t Tpad, int p, int d) {  // halfs inside one plane
-    return (((((int64_t)hd * (Tpad >> 5) + (p >> 5)) * 2 + (d >> 4)) * 2 + ((d >> 3) & 1)) * 32 + (p & 31)) * 8 + (d & 7);
-}
-__device__ __forceinline__ int64_t vt_off(int hd, int64_t Tpad, int p, int d) {
-    const int k = p & 15;
-    return ((((int64_t)hd * (Tpad >> 4) + (p >> 4)) * 2 + ((k >> 2) & 1)) * 32 + d) * 8 + (k & 3) + 4 * (k >> 3);
-}
-
 constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 16-B accesses of consecutive tokens hit distinct banks)
 
 // ---------------------------------------------------------------- f16x3 linear layers (wt_gemm.h)
@@ -231,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                                                            const _Float16* __restrict__ Wp, int N,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            _Float16* __restrict__ oh, _Float16* __restrict__ ol,
-                                                           int n_blocks_n, QkvOut qo) {
-    constexpr bool STAGED = (NTW == 3 && TTW == 2 && (EPI == 0 || EPI == 2));  // batch form: results leave through an LDS stage, coalesced
+                                                           int n_blocks_n) {
+    constexpr bool STAGED = (NTW == 3 && TTW == 2 && EPI == 0);  // batch form: results leave through an LDS stage, coalesced
     constexpr int SM = (STAGED && 32 * LN_LD * 4 > XRing<TTW>::BYTES) ? 32 * LN_LD * 4 : XRing<TTW>::BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SM];
     const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
@@ -264,60 +241,12 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                     *reinterpret_cast<f32x4*>(stage + r * LN_LD + fl) = v;
                 }
             __syncthreads();
-            if constexpr (EPI == 2) {
-                const int64_t plane = (int64_t)qo.heads * 32 * qo.Tpad;  // halfs per plane (q, k and vt alike)
-                if (nb < 2) {  // Q or K: (head, token, 4-dim chunk) order -> 8 consecutive tokens fill 128 contiguous bytes of each fragment half
-                    _Float16* const dst = nb == 0 ? qo.q : qo.k;
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        const int f = threadIdx.x + 256 * k, head = f >> 8, row = (f >> 3) & 31, c8 = f & 7;
-                        const int64_t tok = m0 + tt * 32 + row;
-                        const int p = tok < T ? qo.pos[tok] : -1;
-                        if (p >= 0) {
-                            half4 hi, lo;
-                            split_act4(*reinterpret_cast<const f32x4*>(stage + row * LN_LD + head * 32 + c8 * 4), hi, lo);
-                            const int64_t at = qk_off(head, qo.Tpad, p, c8 * 4);
-                            *reinterpret_cast<half4*>(dst + at) = hi;
-                            *reinterpret_cast<half4*>(dst + plane + at) = lo;
-                        }
-                    }
-                } else {  // V, transposed: (feature, 4 consecutive tokens) per thread -> 8 bytes of one fragment row
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        const int f = threadIdx.x + 256 * k, feat = f >> 3, tg = f & 7, head = feat >> 5, dim = feat & 31;
-                        const int64_t tok0 = m0 + tt * 32 + tg * 4;
-                        if (tok0 < T) {
-                            f32x4 v;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = stage[(tg * 4 + i) * LN_LD + feat];
-                            half4 hi, lo;
-                            split_act4(v, hi, lo);
-                            const int p0 = qo.pos[tok0];
-                            const bool whole = tok0 + 3 < T && p0 >= 0 && (p0 & 3) == 0 && qo.pos[tok0 + 3] == p0 + 3;
-                            if (whole) {  // the same sequence, 4-aligned: the four keys are consecutive in the fragment
-                                const int64_t at = vt_off(head, qo.Tpad, p0, dim);
-                                *reinterpret_cast<half4*>(qo.vt + at) = hi;
-                                *reinterpret_cast<half4*>(qo.vt + plane + at) = lo;
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (tok0 + i < T && qo.pos[tok0 + i] >= 0) {
-                                        const int64_t at = vt_off(head, qo.Tpad, qo.pos[tok0 + i], dim);
-                                        qo.vt[at] = hi[i];
-                                        qo.vt[plane + at] = lo[i];
-                                    }
-                            }
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    const int f = threadIdx.x + 256 * k, row = f / 96, c = f - row * 96;
-                    const int64_t tok = m0 + tt * 32 + row;
-                    if (tok < T)
-                        *reinterpret_cast<f32x4*>(out + tok * N + n0 + c * 4) = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
-                }
+            for (int k = 0; k < 12; ++k) {
+                const int f = threadIdx.x + 256 * k, row = f / 96, c = f - row * 96;
+                const int64_t tok = m0 + tt * 32 + row;
+                if (tok < T)
+                    *reinterpret_cast<f32x4*>(out + tok * N + n0 + c * 4) = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
             }
             if (tt == 0) __syncthreads();
         }
@@ -338,28 +267,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                    if (EPI == 2) {  // QKV planes, lane-per-token form (small batches only)
-                        const int p = qo.pos[tok];
-                        if (p >= 0) {
-                            half4 hi, lo;
-                            split_act4(v, hi, lo);
-                            const int part = feat / 384, fi = feat - part * 384, head = fi >> 5, dim = fi & 31;
-                            const int64_t plane = (int64_t)qo.heads * 32 * qo.Tpad;
-                            if (part < 2) {
-                                _Float16* const dst = part == 0 ? qo.q : qo.k;
-                                const int64_t at = qk_off(head, qo.Tpad, p, dim);
-                                *reinterpret_cast<half4*>(dst + at) = hi;
-                                *reinterpret_cast<half4*>(dst + plane + at) = lo;
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const int64_t at = vt_off(head, qo.Tpad, p, dim + j);
-                                    qo.vt[at] = hi[j];
-                                    qo.vt[plane + at] = lo[j];
-                                }
-                            }
-                        }
-                    } else if (EPI == 1) {
+                    if (EPI == 1) {
                         half4 hi, lo;
                         half2w a, b, c, d;
                         split_pair_prescaled(gelu16_wt(v[0]), gelu16_wt(v[1]), a, b);
@@ -1266,210 +1174,6 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
     ICREC_STAMP(0, 5);
 }
 
-// ---------------------------------------------------------------- attention, operands straight from HBM/L2 planes
-// The batch- and small-batch form of f16x3 attention.  The QKV projection's epilogue already produced what the MFMAs
-// consume (QkvOut: Q and K as head-major f16 hi/lo planes, V transposed with the keys in MFMA order), so a wave needs
-// no LDS staging, no conversion and no barrier: it owns one (sequence, head, 32-query block), loads its fragments
-// with 16-byte global loads (K: 32 keys x 16 B of contiguous 64-byte rows; V^T: 32 dims x 16 B) and runs
-//   S^T = K.Q^T (keys on the accumulator rows)  ->  softmax on its lanes  ->  O = P.V with P fed back from the
-//   accumulators,
-// the arithmetic of attention_x3_kernel (single accumulator, scales 16 / 16 / 1024 folded into constants).  Waves are
-// independent, so several per SIMD overlap each other's load latency; the four waves of a workgroup are consecutive
-// query blocks — normally of one sequence — and share its K / V^T through L1.
-//   padcu[s]: first padded position of sequence s (a multiple of 32): query block g of the batch starts at padded
-//   position 32 g.  NKT: 2 = sequences of <= 64 tokens, 8 = longer ones (a wave of the other bucket exits at once).
-template <int NKT>
-__global__ __launch_bounds__(256, NKT == 8 ? 2 : 4) void attention_wt_kernel(QkvOut qo, const int32_t* __restrict__ cu,
-                                                           const int32_t* __restrict__ padcu, int n_seqs, int H,
-                                                           float scale_log2e, _Float16* __restrict__ ch,
-                                                           _Float16* __restrict__ cl) {
-    __shared__ __attribute__((aligned(16))) _Float16 Ob[4][2 * 32 * 32];  // per-wave output tile (hi | lo)
-    __shared__ float Ls[4][32];
-    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-    const int hd = blockIdx.y;
-    const int p0 = (blockIdx.x * 4 + wave) * 32;  // padded position of this wave's first query
-    if (p0 >= padcu[n_seqs]) return;
-    int s;
-    {
-        int lo = 0, hi = n_seqs;  // largest s with padcu[s] <= p0
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (padcu[mid] <= p0) lo = mid; else hi = mid;
-        }
-        s = lo;
-    }
-    const int t0 = cu[s], L = cu[s + 1] - t0, pbase = padcu[s];
-    const int nkt = (L + 31) >> 5;
-    if (NKT == 2 ? nkt > 2 : nkt <= 2) return;  // the other bucket's sequence
-    const int qb = (p0 - pbase) >> 5;
-    if (qb >= nkt) return;
-    const int64_t plane = (int64_t)qo.heads * 32 * qo.Tpad;  // halfs per plane
-    const unsigned lo8 = lane * 8;                            // lane = (h << 5) | r: this lane's 16 bytes of a fragment
-
-    half8 qh[2], ql[2];  // rows past the sequence end are padding (never stored, they only feed their own lanes)
-    {
-        const _Float16* qp = qo.q + ((int64_t)hd * (qo.Tpad >> 5) + (p0 >> 5)) * 2048 + lo8;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qh[ks] = *reinterpret_cast<const half8*>(qp + ks * 512);
-            ql[ks] = *reinterpret_cast<const half8*>(qp + plane + ks * 512);
-        }
-    }
-    const _Float16* const kbase = qo.k + ((int64_t)hd * (qo.Tpad >> 5) + (pbase >> 5)) * 2048 + lo8;
-    f32x16 sc[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
-        if (kt < nkt) {
-            const _Float16* kp = kbase + kt * 2048;  // keys past the end of the last tile: padding, masked below
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const half8 kh = *reinterpret_cast<const half8*>(kp + ks * 512);
-                const half8 kl = *reinterpret_cast<const half8*>(kp + plane + ks * 512);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sc[kt], 0, 0, 0);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc[kt], 0, 0, 0);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc[kt], 0, 0, 0);
-            }
-        }
-    }
-    const float cs = scale_log2e * (1.0f / 256.0f);  // scores in log2 units from S' = 256 S
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (kt < nkt) {
-            const bool last = kt == nkt - 1;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = sc[kt][e] * cs;
-                if (last && kt * 32 + acc_row(e, lane) >= L) v = -INFINITY;
-                sc[kt][e] = v;
-                mx = fmaxf(mx, v);
-            }
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) - 10.0f;  // p' = 2^(v - max + 10) = 1024 p
-    float lsum = 0.0f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
-                sc[kt][e] = p;
-                lsum = lsum + p;
-            }
-        }
-    }
-    {
-        const float other = __shfl_xor(lsum, 32, 64);
-        lsum = h == 0 ? lsum + other : other + lsum;
-    }
-    if (h == 0) Ls[wave][r] = lsum;
-
-    const _Float16* const vbase = qo.vt + ((int64_t)hd * (qo.Tpad >> 4) + (pbase >> 4)) * 512 + lo8;
-    f32x16 o;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const half8 vh = *reinterpret_cast<const half8*>(vbase + (kt * 2 + ks) * 512);
-                const half8 vl = *reinterpret_cast<const half8*>(vbase + plane + (kt * 2 + ks) * 512);
-                half8 ph, pl;
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    half2w a, b;
-                    split_pair_prescaled(sc[kt][8 * ks + j], sc[kt][8 * ks + j + 1], a, b);
-                    ph[j] = a[0]; ph[j + 1] = a[1];
-                    pl[j] = b[0]; pl[j + 1] = b[1];
-                }
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o, 0, 0, 0);
-            }
-        }
-    }
-    // park the wave's 32 x 32 output tile (hi and lo planes) in LDS row-major, then write it out 16 B per lane
-    _Float16* ob = Ob[wave];
-#pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-        const int q0 = acc_row(e, lane), q1 = acc_row(e + 1, lane);
-        const float v0 = o[e] * (0.0625f * __builtin_amdgcn_rcpf(Ls[wave][q0]));
-        const float v1 = o[e + 1] * (0.0625f * __builtin_amdgcn_rcpf(Ls[wave][q1]));
-        half2w hi, lo;
-        split_pair_prescaled(v0 * WT_SA, v1 * WT_SA, hi, lo);
-        ob[q0 * 32 + r] = hi[0];
-        ob[q1 * 32 + r] = hi[1];
-        ob[32 * 32 + q0 * 32 + r] = lo[0];
-        ob[32 * 32 + q1 * 32 + r] = lo[1];
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int id = lane + 64 * t, qrow = id >> 2, c8 = (id & 3) * 8;
-        const int tq = qb * 32 + qrow;
-        if (tq < L) {
-            const size_t at = (size_t)(t0 + tq) * H + hd * DH + c8;
-            *reinterpret_cast<u32x4*>(ch + at) = *reinterpret_cast<const u32x4*>(ob + qrow * 32 + c8);
-            *reinterpret_cast<u32x4*>(cl + at) = *reinterpret_cast<const u32x4*>(ob + 32 * 32 + qrow * 32 + c8);
-        }
-    }
-}
-
-// padded layout of a packed batch: padcu[s] = sum of the lengths of sequences < s, each rounded up to 32;
-// pos[t] = padcu[seq(t)] + t - cu[seq(t)].  One workgroup (sequential chunks + one LDS scan), then a flat map.
-__global__ __launch_bounds__(1024) void pad_scan_kernel(const int32_t* __restrict__ cu, int n_seqs,
-                                                        int32_t* __restrict__ padcu) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x, per = (n_seqs + 1023) / 1024;
-    const int b = t * per, e_ = b + per < n_seqs ? b + per : n_seqs;
-    int sum = 0;
-    for (int i = b; i < e_; ++i) sum += (cu[i + 1] - cu[i] + 31) & ~31;
-    part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan
-        const int v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = t ? part[t - 1] : 0;
-    for (int i = b; i < e_; ++i) {
-        padcu[i] = run;
-        run += (cu[i + 1] - cu[i] + 31) & ~31;
-    }
-    if (t == 1023) padcu[n_seqs] = part[1023];
-}
-// V^T rows are read in whole 32-key tiles: the slots between a sequence's last key and the end of its last tile must
-// hold finite values (they meet p = 0).  One workgroup per sequence zeroes them in all 2 x 384 rows.
-__global__ __launch_bounds__(256) void vt_zero_pad_kernel(const int32_t* __restrict__ cu,
-                                                          const int32_t* __restrict__ padcu, _Float16* __restrict__ vt,
-                                                          int64_t Tpad, int heads) {
-    const int s = blockIdx.x, L = cu[s + 1] - cu[s], pb = padcu[s];
-    const int end = (L + 31) & ~31;
-    const int64_t plane = (int64_t)heads * 32 * Tpad;
-    for (int row = threadIdx.x; row < heads * 32; row += 256)
-        for (int p = L; p < end; ++p) {
-            const int64_t at = vt_off(row >> 5, Tpad, pb + p, row & 31);
-            vt[at] = (_Float16)0.0f;
-            vt[plane + at] = (_Float16)0.0f;
-        }
-}
-__global__ __launch_bounds__(256) void pad_pos_kernel(const int32_t* __restrict__ cu,
-                                                      const int32_t* __restrict__ padcu, int n_seqs, int T,
-                                                      int32_t* __restrict__ pos) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    if (t >= cu[n_seqs]) {  // a row outside every sequence (hipGraph replays run a fixed row count): it owns no V^T slot —
-        pos[t] = -1;        // its values (possibly garbage: attention never wrote its context) must not land in a real
-        return;             // sequence's padding
-    }
-    const int s = find_seq(cu, n_seqs, t);
-    pos[t] = padcu[s] + t - cu[s];
-}
-
 // ---------------------------------------------------------------- mean pooling + L2 normalise
 // sentence_transformers Pooling(mean): sum_t h_t / clamp(count, 1e-9); then n_norm times
 // x / max(|x|_2, 1e-12) (Normalize module, normalize_embeddings=True).  One workgroup of
@@ -1539,24 +1243,14 @@ static size_t weight_count(const icrec_bert_cfg* c) {
 
 struct EncWs {
     size_t x, xs, qkv, ctx, t1, h, total;
-    // F16X3: the qkv region holds the QKV projection's planes instead of fp32 rows (QkvOut), + the padded-layout maps
-    size_t q, k, vt, pos, padcu;
-    int64_t Tpad;
 };
-static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T, int64_t n_seqs) {
+static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     EncWs w;
     size_t o = 0;
     w.x = o;   o += al((size_t)T * c.hidden * 4);
     w.xs = o;  o += al((size_t)T * c.hidden * 4);        // x as f16 hi/lo planes (F16X3)
-    w.Tpad = (T + 31 * n_seqs + 31) & ~(int64_t)31;       // every sequence padded to a multiple of 32 keys, at most
-    w.qkv = o;
-    w.q = o;     o += al((size_t)w.Tpad * c.hidden * 4);  // two f16 planes over the padded layout
-    w.k = o;     o += al((size_t)w.Tpad * c.hidden * 4);
-    w.vt = o;    o += al((size_t)w.Tpad * c.hidden * 4);
-    w.pos = o;   o += al((size_t)T * 4);
-    w.padcu = o; o += al((size_t)(n_seqs + 1) * 4);
-    if (o - w.qkv < al((size_t)T * 3 * c.hidden * 4)) o = w.qkv + al((size_t)T * 3 * c.hidden * 4);  // fp32 rows (F32 mode)
+    w.qkv = o; o += al((size_t)T * 3 * c.hidden * 4);
     w.ctx = o; o += al((size_t)T * c.hidden * 4);        // fp32 ctx, or its two f16 planes
     w.t1 = o;  o += al((size_t)T * c.hidden * 4);
     w.h = o;   o += al((size_t)T * c.intermediate * 4);  // fp32 h, or its two f16 planes
@@ -1581,16 +1275,15 @@ static void launch_linear(const float* A, int M, int K, const float* W, int N, c
 // wave).  Per-output arithmetic is the same chain in both, so a request encodes to the same bits either way.
 template <int EPI>
 static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int K, const _Float16* Wp, int N,
-                             const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st,
-                             const QkvOut& qo = QkvOut{}) {
+                             const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
     if (T <= X3_SMALL_M) {
         const int nbn = N / 128;
         hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
-                           Wp, N, bias, out, oh, ol, nbn, qo);
+                           Wp, N, bias, out, oh, ol, nbn);
     } else {
         const int nbn = N / 384;
         hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, EPI>), dim3(((T + 63) / 64) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
-                           Wp, N, bias, out, oh, ol, nbn, qo);
+                           Wp, N, bias, out, oh, ol, nbn);
     }
 }
 
@@ -1711,7 +1404,7 @@ int icrec_encoder_destroy(icrec_encoder* h) {
 size_t icrec_encode_workspace_bytes(const icrec_encoder* h, int64_t total_tokens, int32_t n_seqs) {
     const Encoder* e = reinterpret_cast<const Encoder*>(h);
     if (!e || total_tokens < 1 || n_seqs < 1) return 0;
-    return enc_ws(e->cfg, total_tokens, n_seqs).total;
+    return enc_ws(e->cfg, total_tokens).total;
 }
 
 // How icrec_encode splits a batch of T tokens (f16x3 mode): [0, main) through the batch kernels in whole rounds of
@@ -1744,7 +1437,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     ICREC_REQUIRE(n_seqs >= 1 && T64 >= n_seqs && T64 < (1ll << 31), "icrec_encode: bad n_seqs/total_tokens (%d, %lld)", n_seqs, (long long)T64);
     ICREC_REQUIRE(max_seqlen >= 1 && max_seqlen <= 256 && max_seqlen <= e->cfg.max_position, "icrec_encode: max_seqlen must be in [1, 256] (got %d)", max_seqlen);
     const int T = (int)T64;
-    const EncWs w = enc_ws(e->cfg, T, n_seqs);
+    const EncWs w = enc_ws(e->cfg, T);
     if (!ws || ws_bytes < w.total) {
         set_error("icrec_encode: workspace too small (%zu < %zu)", ws_bytes, w.total);
         return ICREC_ENOMEM;
@@ -1775,21 +1468,6 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     _Float16* hh = reinterpret_cast<_Float16*>(hb);
     _Float16* hl = hh + (size_t)T * I;
 
-    QkvOut qo{};
-    if (x3) {  // the padded layout of this batch (attention's V^T planes) and where the QKV planes live
-        qo.q = reinterpret_cast<_Float16*>(base + w.q);
-        qo.k = reinterpret_cast<_Float16*>(base + w.k);
-        qo.vt = reinterpret_cast<_Float16*>(base + w.vt);
-        qo.T = T;
-        qo.Tpad = w.Tpad;
-        qo.heads = c.heads;
-        int32_t* pos = reinterpret_cast<int32_t*>(base + w.pos);
-        int32_t* padcu = reinterpret_cast<int32_t*>(base + w.padcu);
-        qo.pos = pos;
-        hipLaunchKernelGGL(pad_scan_kernel, dim3(1), dim3(1024), 0, st, cu_dev, n_seqs, padcu);
-        hipLaunchKernelGGL(pad_pos_kernel, dim3((T + 255) / 256), dim3(256), 0, st, cu_dev, padcu, n_seqs, T, pos);
-        hipLaunchKernelGGL(vt_zero_pad_kernel, dim3(n_seqs), dim3(256), 0, st, cu_dev, padcu, qo.vt, w.Tpad, c.heads);
-    }
     if (x3)
         hipLaunchKernelGGL((embed_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T,
                            e->word, e->pos, e->type, e->eg, e->eb, c.ln_eps, c.vocab_size, c.max_position, x, xh, xl);
@@ -1803,10 +1481,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // CU, a short remainder [T_main, T) through the small-batch kernels (same arithmetic, same bits) instead
             // of costing every batch kernel an extra, almost empty round.
             auto qkv_stage = [&](int r0, int Tn) {
-                QkvOut o = qo;  // token indices inside the launch are relative to r0; `pos` holds absolute padded positions
-                o.pos += r0;
-                launch_wt_linear<2>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv, nullptr,
-                                    nullptr, nullptr, st, o);
+                launch_wt_linear<0>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv,
+                                    qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
             };
             auto post_stage = [&](int r0, int Tn) -> int {
                 float* const xr = x + (size_t)r0 * H;
@@ -1839,14 +1515,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             };
             qkv_stage(0, T_main);
             if (T_tail) qkv_stage(T_main, T_tail);
-            {
-                const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
-                const dim3 grid((unsigned)((w.Tpad / 32 + 3) / 4), c.heads);
-                const int32_t* padcu = reinterpret_cast<const int32_t*>(base + w.padcu);
-                hipLaunchKernelGGL((attention_wt_kernel<2>), grid, dim3(256), 0, st, qo, cu_dev, padcu, n_seqs, H, sl2e, ch, cl);
-                if (max_seqlen > 64)
-                    hipLaunchKernelGGL((attention_wt_kernel<8>), grid, dim3(256), 0, st, qo, cu_dev, padcu, n_seqs, H, sl2e, ch, cl);
-            }
+            launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
             if (int rc_ = post_stage(0, T_main)) return rc_;
             if (T_tail)
                 if (int rc_ = post_stage(T_main, T_tail)) return rc_;

@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
         dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 30});
         dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 30});
         reinit();
-        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3, QkvOut{});
+        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         hipDeviceSynchronize();
         dump("qkv wave0", nb * 3, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
         hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
@@ -143,7 +143,7 @@ int main(int argc, char** argv) {
         }
         reinit();
         timeit("qkv wt_linear<3,2,2,0> N=1152", [&] {
-            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3, QkvOut{});
+            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         }, 2.0 * T * H * 3 * H);
         timeit("attn-out + LN wt_linear_ln<2>", [&] {
             hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
