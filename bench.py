@@ -197,7 +197,17 @@ def main() -> None:
     del shard
     # N > 1: the exchange runs inside libicrec (icrec_search_sharded: two ncclAllGathers on the step's stream);
     # torch.distributed only carries the 128-byte rendezvous id, the barrier and the max-over-ranks of the clock
-    comm = NativeComm.from_process_group(dev) if (world > 1 and not rehearsal) else None
+    comm, comm_note = None, None
+    if world > 1 and not rehearsal:
+        try:
+            comm = NativeComm.from_process_group(dev)
+        except Exception as exc:  # noqa: BLE001 - keep the scaling run alive: same kernels, collectives through torch.distributed
+            comm_note = f"icrec_comm_init failed ({type(exc).__name__}: {exc}); exchange through torch.distributed (RCCL) instead"
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must take the same path
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
     search = ShardedSearch(backend, lo, hi, comm=comm)
 
     # ---- this rank's batch of user contexts as packed token ids, resident in HBM
@@ -418,6 +428,8 @@ def main() -> None:
                 if world > 1 else "single GPU",
             },
             "rehearsal_not_a_measurement": True if rehearsal else None,
+            "exchange": None if world == 1 else ("icrec_search_sharded (RCCL inside libicrec)" if comm is not None else
+                                                 (comm_note or "torch.distributed collectives (gloo rehearsal)")),
             "p50_latency_ms_single_request": p50_ms,
             "p50_latency_ms_single_request_without_hipgraph": p50_plain_ms,
             "single_request_tokens": int(cu_h[1]),
