@@ -320,6 +320,9 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
 #pragma unroll
     for (int t0 = 0; t0 < 2; t0 += PT) {
         const int64_t row0 = m0 + t0 * 32;
+        const int sb = 32 + 8 * (t0 / PT);  // diagnostic stamp base of this pass
+        (void)sb;
+        ICREC_STAMP(0, sb); ICREC_STAMP(4, sb);
         {   // residual rows in: 16-B chunks in flat order (a wave instruction covers 1 KB of at most two rows)
             f32x4 v[PER];
 #pragma unroll
@@ -335,7 +338,9 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
                 *reinterpret_cast<f32x4*>(stage + row * LN_LD + c * 4) = v[k];
             }
         }
+        ICREC_STAMP(0, sb + 1); ICREC_STAMP(4, sb + 1);
         sync();
+        ICREC_STAMP(0, sb + 2); ICREC_STAMP(4, sb + 2);
         float part[PT];
         if (active) {
 #pragma unroll
@@ -363,6 +368,7 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
                 if (h == 0) red[(p * 32 + r) * 4 + q] = part[p];
             }
         }
+        ICREC_STAMP(0, sb + 3); ICREC_STAMP(4, sb + 3);
         sync();
         if (active) {
 #pragma unroll
@@ -382,6 +388,7 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
                 if (h == 0) red[ROWS * 4 + (p * 32 + r) * 4 + q] = sq;
             }
         }
+        ICREC_STAMP(0, sb + 4); ICREC_STAMP(4, sb + 4);
         sync();
         if (active) {
 #pragma unroll
@@ -403,6 +410,7 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
                     }
             }
         }
+        ICREC_STAMP(0, sb + 5); ICREC_STAMP(4, sb + 5);
         sync();
         {   // normalised rows out, flat: fp32 x (16 B per thread) and its two f16 planes (8 B each)
 #pragma unroll
@@ -419,6 +427,7 @@ __device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, i
                 }
             }
         }
+        ICREC_STAMP(0, sb + 6); ICREC_STAMP(4, sb + 6);
         if (t0 + PT < 2) sync();  // the stage is rewritten by the next pass
     }
 }

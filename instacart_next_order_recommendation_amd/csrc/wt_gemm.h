@@ -159,7 +159,7 @@ __device__ unsigned long long g_stamps[1 << 22];
 #define ICREC_STAMP(slot_wave, k)                                                                        \
     do {                                                                                                 \
         if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x >> 6) == (slot_wave))                           \
-            g_stamps[((size_t)blockIdx.x * 2 + ((slot_wave) ? 1 : 0)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+            g_stamps[((size_t)blockIdx.x * 2 + ((slot_wave) ? 1 : 0)) * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define ICREC_STAMP(slot_wave, k) do { } while (0)

@@ -77,38 +77,39 @@ int main(int argc, char** argv) {
 #ifdef ICREC_STAMPS
     // phase stamps (s_memtime shader-clock ticks): median over blocks of each interval
     auto dump = [&](const char* name, int nblocks, int which, std::vector<int> ks) {
-        std::vector<unsigned long long> hs((size_t)nblocks * 64);
+        std::vector<unsigned long long> hs((size_t)nblocks * 128);
         hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_stamps), hs.size() * 8);
         printf("%s: median cycles between stamps", name);
         for (size_t a = 0; a + 1 < ks.size(); ++a) {
             std::vector<long long> d;
             for (int b = 0; b < nblocks; ++b) {
-                const unsigned long long t0 = hs[((size_t)b * 2 + which) * 32 + ks[a]], t1 = hs[((size_t)b * 2 + which) * 32 + ks[a + 1]];
+                const unsigned long long t0 = hs[((size_t)b * 2 + which) * 64 + ks[a]], t1 = hs[((size_t)b * 2 + which) * 64 + ks[a + 1]];
                 d.push_back((long long)(t1 - t0));
             }
             std::sort(d.begin(), d.end());
             printf(" [%d->%d] %lld", ks[a], ks[a + 1], d[d.size() / 2]);
         }
         std::vector<long long> dur; unsigned long long mn = ~0ull, mx = 0;
-        for (int b = 0; b < nblocks; ++b) { unsigned long long t0 = hs[((size_t)b * 2 + which) * 32 + ks.front()], t1 = hs[((size_t)b * 2 + which) * 32 + ks.back()]; dur.push_back((long long)(t1 - t0)); mn = std::min(mn, t0); mx = std::max(mx, t1); }
+        for (int b = 0; b < nblocks; ++b) { unsigned long long t0 = hs[((size_t)b * 2 + which) * 64 + ks.front()], t1 = hs[((size_t)b * 2 + which) * 64 + ks.back()]; dur.push_back((long long)(t1 - t0)); mn = std::min(mn, t0); mx = std::max(mx, t1); }
         std::sort(dur.begin(), dur.end());
         printf("  | block median %lld p90 %lld, kernel span %llu\n", dur[dur.size() / 2], dur[dur.size() * 9 / 10], mx - mn);
     };
-    {
-        const int T = 131072, nb = T / 64;
+    for (int T : {2048, 16384, 131072}) {
+        const int nb = T / 64;
+        printf("==== T = %d (%d blocks of 64 tokens)\n", T, nb);
         auto kern = ffn_fused2_kernel<0>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
         for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, x, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
         hipDeviceSynchronize();
-        dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 30});
-        dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 30});
+        dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 32, 33, 34, 35, 36, 37, 38, 30});
+        dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 32, 33, 34, 35, 36, 37, 38, 30});
         reinit();
         hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         hipDeviceSynchronize();
         dump("qkv wave0", nb * 3, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
         hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, x, xh, xl, g, bn, 1e-12f);
         hipDeviceSynchronize();
-        dump("attn-out+LN wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
+        dump("attn-out+LN wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 32, 33, 34, 35, 36, 37, 38, 40, 41, 42, 43, 44, 45, 46, 30});
         reinit();
         {   // attention, long bucket: 512 sequences of 200 tokens
             const int nseq = 512, Ls = 200;
@@ -124,9 +125,10 @@ int main(int argc, char** argv) {
             timeit("attention_x3<8,8> 512 seq x 200 tok", [&] {
                 hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl);
             }, 4.0 * nseq * 12 * Ls * Ls * 32);
+            hipFree(cud);
         }
-        return 0;
     }
+    return 0;
 #endif
     for (int T : {T0, 131072, 16384}) {
         const double ffn_flops = 4.0 * T * H * I;
