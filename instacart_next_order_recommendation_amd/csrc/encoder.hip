@@ -49,12 +49,13 @@ __device__ __forceinline__ void ln_row(float (&v)[H / 64], const float* __restri
     for (int j = 0; j < H / 64; ++j) {
         const int i = lane + 64 * j;
         const float y = fmaf((v[j] - mean) * rstd, g[i], b[i]);
-        out[i] = y;
-        if (SPLIT) {
+        if (SPLIT) {  // f16x3 mode: the residual stream exists only as its two planes
             _Float16 hi, lo;
             split_act(y, hi, lo);
             oh[i] = hi;
             ol[i] = lo;
+        } else {
+            out[i] = y;
         }
     }
 }
@@ -194,251 +195,233 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
     }
 }
 
-constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 16-B accesses of consecutive tokens hit distinct banks)
+// ---------------------------------------------------------------- residual stream + LayerNorm of the f16x3 engine
+// In f16x3 mode the residual stream x lives in HBM ONLY as its two f16 planes (xh, xl: 16 x to 22 significant bits,
+// wt_gemm.h) — the planes every GEMM reads anyway.  The two LayerNorm sites of a layer (tf:292 attention output,
+// tf:350 FFN output: LN(dense(.) + bias + x)) start their accumulators from the residual instead of adding it at
+// the end:
+//     acc0 = fmaf(float(xh) + float(xl), 1024, bias * 2^14)      (hi + lo is exact in fp32; one rounding)
+//     acc  = acc0 + the k-steps of the GEMM, ascending           (units of 2^-14, like every accumulator of the engine)
+//     v    = acc * 2^-14                                         (exact)
+// then the engine's LayerNorm order over the 384 features of a token.  Wave q (0..3 of the waves holding
+// accumulators) owns features q*96 .. q*96+95: lane (r, h) holds, for token tile tt, the 48 values of token
+// tt*32 + r at features q*96 + i*32 + 8g + 4h + j (i < 3, g < 4, j < 4):
+//   part(q, h) = sum over (i, g, j), i outermost, of v            sequential fp32 adds from 0
+//   sum        = ((P0 + P1) + P2) + P3,   Pq = part(q, 0) + part(q, 1)
+//   mean = sum / 384;   d = v - mean;   the same tree over fmaf(d, d, .) chains;   var = that / 384
+//   y = fmaf(d * (1 / sqrtf(var + eps)), gamma, beta);   planes = split(16 y)
+// (ln_wt_kernel is the unfused form with the same order — same bits.)  Compared with an fp32 copy of x beside the
+// planes this drops 8 of the 12 bytes per element every LayerNorm site moved, and the residual needs no global
+// read where the planes are already in LDS (fused FFN).
+//
+// Global memory is touched only by coalesced accesses: a lane-per-token access pattern costs 4x the whole K loop
+// (in-kernel stamps: 73k cycles per block).  Each wave transposes its own [32 tokens x 96 features] of one plane
+// through a PRIVATE 6.5 KB LDS tile (rows of 192 B + 16 B pad): no workgroup barrier, 192 contiguous bytes per
+// token row on the global side.  LDS instructions of one wave execute in order; lds_order() keeps the compiler
+// from reordering across the hand-over and waits for the data.
+constexpr int LNT_ROW = 208;                        // bytes per tile row: 96 halfs + 16 B
+constexpr int LNT_TILE = 32 * LNT_ROW;              // one wave's tile
+constexpr int LNT_RED = 2 * 64 * 4 * 4;             // the two 4-partial exchanges: [2][64 tokens][4 waves] floats
+constexpr int LNT_PAR = 2 * 384 * 4;                // gamma, beta
+constexpr int LNT_BYTES = LNT_RED + 4 * LNT_TILE + LNT_PAR;   // 31,744 B
 
-// ---------------------------------------------------------------- f16x3 linear layers (wt_gemm.h)
-// out^T = W . X^T with the weights streamed straight from L2 into registers (packed fragment order) and the
-// token slab staged through LDS.  Block = 4 waves; wave q owns NTW 32-feature tiles x TTW 32-token tiles.
-//   EPI 0: out fp32 [T, N] = acc * 2^-14 + bias           (QKV; attention-out / FFN-down of small batches)
-//   EPI 1: erf-GELU (tf:336), result as f16 hi/lo planes   (FFN-up of small batches)
-// Each lane holds 4 consecutive features of one token per register group: 16-B (fp32) / 8-B (planes) stores.
-template <int NTW, int TTW, int D, int EPI>
-__global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __restrict__ Xh,
-                                                           const _Float16* __restrict__ Xl, int T, int K,
-                                                           const _Float16* __restrict__ Wp, int N,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           _Float16* __restrict__ oh, _Float16* __restrict__ ol,
-                                                           int n_blocks_n) {
-    constexpr bool STAGED = (NTW == 3 && TTW == 2 && EPI == 0);  // batch form: results leave through an LDS stage, coalesced
-    constexpr int SM = (STAGED && 32 * LN_LD * 4 > XRing<TTW>::BYTES) ? 32 * LN_LD * 4 : XRing<TTW>::BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SM];
-    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-    // the n_blocks_n workgroups that read the same token rows get consecutive logical ids = the same XCD = one L2
-    // (PMC: without the remap the QKV launch fetched its activations three times, 930 MB instead of ~330 MB)
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
-    const int64_t m0 = (int64_t)mt * (32 * TTW);
-    const int nt0 = (nb * 4 + q) * NTW;
-    f32x16 acc[NTW][TTW];
-    wt_kloop<NTW, TTW, D>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);
-    if constexpr (STAGED) {
-        // [384 features x 32 tokens] per pass -> stage[token][feature] (16-B LDS writes), then 16-B chunks in flat
-        // order: every wave store instruction writes 1 KB of at most two output rows.  (Storing 16 B per lane with
-        // the lanes 4,608 B apart took as long as the whole K loop: 32k of 69k cycles per block by in-kernel stamps.)
-        float* const stage = reinterpret_cast<float*>(smem);
-        const int n0 = nb * 384;
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ float res_init_val(_Float16 hi, _Float16 lo, float b) {
+    return fmaf((float)hi + (float)lo, WT_SW, b * (WT_SA * WT_SW));
+}
+
+// acc0 of a [96-feature x 64-token] wave tile from the residual planes in global memory.  `tile`: this wave's
+// LNT_TILE bytes of LDS.
+__device__ __forceinline__ void wt_res_init_global(f32x16 (&acc)[3][2], int q, const float* __restrict__ bias,
+                                                   const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                   int64_t m0, int64_t T, char* tile) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    u32x4 v[2][2][6];
+    int lpos[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // 16-B chunk f of the wave's [32 rows][12 chunks]: 12 lanes cover one row's 192 B
+        const int f = lane + 64 * k, row = f / 12, c = f - row * 12;
+        lpos[k] = row * LNT_ROW + c * 16;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
+            int64_t g = m0 + tt * 32 + row;
+            g = g < T ? g : T - 1;
+            const int64_t off = g * 384 + q * 96 + c * 8;
+            v[tt][0][k] = *reinterpret_cast<const u32x4*>(xh + off);
+            v[tt][1][k] = *reinterpret_cast<const u32x4*>(xl + off);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x4*>(tile + lpos[k]) = v[tt][pl][k];
+            lds_order();
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int fl = q * 96 + i * 32 + 8 * g + 4 * h;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n0 + fl);
-                    f32x4 v;
+                    const int fl = i * 32 + 8 * g + 4 * h;
+                    const half4 a = *reinterpret_cast<const half4*>(tile + r * LNT_ROW + fl * 2);
+                    if (pl == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                    *reinterpret_cast<f32x4*>(stage + r * LN_LD + fl) = v;
-                }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const int f = threadIdx.x + 256 * k, row = f / 96, c = f - row * 96;
-                const int64_t tok = m0 + tt * 32 + row;
-                if (tok < T)
-                    *reinterpret_cast<f32x4*>(out + tok * N + n0 + c * 4) = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
-            }
-            if (tt == 0) __syncthreads();
-        }
-        ICREC_STAMP(0, 30);
-        return;
-    }
-
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int feat = (nt0 + i) * 32 + 8 * g + 4 * h;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
-#pragma unroll
-            for (int tt = 0; tt < TTW; ++tt) {
-                const int64_t tok = m0 + tt * 32 + r;
-                if (tok < T) {
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                    if (EPI == 1) {
-                        half4 hi, lo;
-                        half2w a, b, c, d;
-                        split_pair_prescaled(gelu16_wt(v[0]), gelu16_wt(v[1]), a, b);
-                        split_pair_prescaled(gelu16_wt(v[2]), gelu16_wt(v[3]), c, d);
-                        hi = half4{a[0], a[1], c[0], c[1]};
-                        lo = half4{b[0], b[1], d[0], d[1]};
-                        *reinterpret_cast<half4*>(oh + tok * N + feat) = hi;
-                        *reinterpret_cast<half4*>(ol + tok * N + feat) = lo;
+                        for (int j = 0; j < 4; ++j) acc[i][tt][4 * g + j] = (float)a[j];
                     } else {
-                        *reinterpret_cast<f32x4*>(out + tok * N + feat) = v;
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + q * 96 + fl);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)  // float(hi) + float(lo) is exact
+                            acc[i][tt][4 * g + j] = fmaf(acc[i][tt][4 * g + j] + (float)a[j], WT_SW, b[j] * (WT_SA * WT_SW));
                     }
                 }
-            }
+            lds_order();
         }
-    ICREC_STAMP(0, 30);
 }
 
-// Residual + LayerNorm (tf:292 / tf:350: LN(dense(.) + bias + x)) on the accumulators of a [384-feature x 64-token]
-// block.  Wave q (0..3 of the waves holding accumulators) owns features q*96 .. q*96+95: lane (r, h) holds, for token
-// tile tt, the 48 values of token tt*32 + r at features q*96 + i*32 + 8g + 4h + j (i < 3, g < 4, j < 4).
-//
-// The engine's LayerNorm reduction order (here and in add_ln_wt_kernel for the unfused path — same bits):
-//   part(q, h) = sum over (i, g, j), i outermost, of v            sequential fp32 adds from 0
-//   sum        = ((P0 + P1) + P2) + P3,   Pq = part(q, 0) + part(q, 1)
-//   mean = sum / 384;   d = v - mean;   the same tree over fmaf(d, d, .) chains;   var = that / 384
-//   y = fmaf(d * (1 / sqrtf(var + eps)), gamma, beta)
-// The statistics never leave the lanes (plus one 4-float exchange between the waves).  Global memory is touched
-// only by FLAT, fully coalesced passes: the residual rows come in and the normalised rows go out through an LDS
-// stage [rows][388 floats] — a lane-per-token 16-byte global access pattern costs 4x the whole K loop (measured with
-// in-kernel stamps: 73k cycles per block).  PT = token tiles per pass (stage = PT * 49,664 B, + 2 KB of reduction
-// scratch), NT = threads of the workgroup, `sync` its barrier; every thread must call, `active` = this wave holds
-// accumulators.
-template <int PT>
-struct LnStage {
-    static constexpr int STAGE_BYTES = PT * 32 * LN_LD * 4;
-    static constexpr int BYTES = STAGE_BYTES + 2 * PT * 32 * 4 * 4;
-};
-template <int PT, int NT, class Sync>
-__device__ __forceinline__ void wt_ln_staged(f32x16 (&acc)[3][2], bool active, int q, const float* __restrict__ bias,
-                                             float* __restrict__ x, _Float16* __restrict__ xh,
-                                             _Float16* __restrict__ xl, int64_t m0, int64_t T,
-                                             const float* __restrict__ gam, const float* __restrict__ bet, float eps,
-                                             char* lds, Sync sync) {
-    static_assert(PT == 1 || PT == 2, "token tiles per pass");
-    constexpr int ROWS = PT * 32, CHUNKS = ROWS * 96, PER = CHUNKS / NT;
-    static_assert(CHUNKS % NT == 0, "flat passes must divide evenly");
-    float* const stage = reinterpret_cast<float*>(lds);
-    float* const red = stage + ROWS * LN_LD;
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+// The same for the single-tile waves of the small-batch kernels: 8-byte loads straight from global memory (a
+// handful of tokens: latency, not bandwidth).
+__device__ __forceinline__ void wt_res_init_direct(f32x16 (&acc)[1][1], int nt0, const float* __restrict__ bias,
+                                                   const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                   int N, int64_t m0, int64_t T) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    int64_t tok = m0 + r;
+    tok = tok < T ? tok : T - 1;
 #pragma unroll
-    for (int t0 = 0; t0 < 2; t0 += PT) {
-        const int64_t row0 = m0 + t0 * 32;
-        const int sb = 32 + 8 * (t0 / PT);  // diagnostic stamp base of this pass
-        (void)sb;
-        ICREC_STAMP(0, sb); ICREC_STAMP(4, sb);
-        {   // residual rows in: 16-B chunks in flat order (a wave instruction covers 1 KB of at most two rows)
-            f32x4 v[PER];
+    for (int g = 0; g < 4; ++g) {
+        const int feat = nt0 * 32 + 8 * g + 4 * h;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
+        const half4 a = *reinterpret_cast<const half4*>(xh + tok * N + feat);
+        const half4 d = *reinterpret_cast<const half4*>(xl + tok * N + feat);
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int f = tid + NT * k, row = f / 96, c = f - row * 96;
-                int64_t g = row0 + row;
-                g = g < T ? g : T - 1;
-                v[k] = *reinterpret_cast<const f32x4*>(x + g * 384 + c * 4);
-            }
+        for (int j = 0; j < 4; ++j) acc[0][0][4 * g + j] = res_init_val(a[j], d[j], b[j]);
+    }
+}
+
+// LayerNorm of a block's accumulators (acc = residual + bias + dense, in units of 2^-14) -> the two planes of x.
+// NT threads call; `active` = this wave holds accumulators (wave-uniform), `sync` = the workgroup barrier.
+// lds: LNT_BYTES.  At least 192 threads must call.
+template <class Sync>
+__device__ __forceinline__ void wt_ln_out(f32x16 (&acc)[3][2], bool active, int q, _Float16* __restrict__ xh,
+                                          _Float16* __restrict__ xl, int64_t m0, int64_t T,
+                                          const float* __restrict__ gam, const float* __restrict__ bet, float eps,
+                                          char* lds, Sync sync) {
+    float* const red = reinterpret_cast<float*>(lds);
+    char* const tile = lds + LNT_RED + q * LNT_TILE;
+    float* const par = reinterpret_cast<float*>(lds + LNT_RED + 4 * LNT_TILE);
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    ICREC_STAMP(0, 32); ICREC_STAMP(4, 32);
+    // gamma / beta -> LDS (visible after the first barrier): each lane needs the 48 values of its half of the wave's 96
+    // features, the same in every lane of the half - as vector loads that is 96 x 1 KB through the texture path per wave
+    // for 768 distinct bytes (measured: the normalise + write-out phase was bound by them)
+    if (threadIdx.x < 192) {
+        const int t = threadIdx.x;
+        *reinterpret_cast<f32x4*>(par + 4 * t) = *reinterpret_cast<const f32x4*>((t < 96 ? gam : bet - 384) + 4 * t);
+    }
+    if (active) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int f = tid + NT * k, row = f / 96, c = f - row * 96;
-                *reinterpret_cast<f32x4*>(stage + row * LN_LD + c * 4) = v[k];
-            }
+        for (int p = 0; p < 2; ++p) {
+            float part = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][p][e] * WT_UNSCALE;
+                    acc[i][p][e] = v;
+                    part = part + v;
+                }
+            part = part + __shfl_xor(part, 32, 64);  // Pq (a + b == b + a exactly: both halves hold the same bits)
+            if (h == 0) red[(p * 32 + r) * 4 + q] = part;
         }
-        ICREC_STAMP(0, sb + 1); ICREC_STAMP(4, sb + 1);
-        sync();
-        ICREC_STAMP(0, sb + 2); ICREC_STAMP(4, sb + 2);
-        float part[PT];
-        if (active) {
+    }
+    ICREC_STAMP(0, 33); ICREC_STAMP(4, 33);
+    sync();
+    if (active) {
 #pragma unroll
-            for (int p = 0; p < PT; ++p) part[p] = 0.0f;
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + (p * 32 + r) * 4);
+            const float mean = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float d = acc[i][p][e] - mean;
+                    acc[i][p][e] = d;
+                    sq = fmaf(d, d, sq);
+                }
+            sq = sq + __shfl_xor(sq, 32, 64);
+            if (h == 0) red[256 + (p * 32 + r) * 4 + q] = sq;
+        }
+    }
+    ICREC_STAMP(0, 34); ICREC_STAMP(4, 34);
+    sync();
+    ICREC_STAMP(0, 35); ICREC_STAMP(4, 35);
+    if (active) {
+        int lpos[6], gpos[6], grow[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int f = lane + 64 * k, row = f / 12, c = f - row * 12;
+            lpos[k] = row * LNT_ROW + c * 16;
+            gpos[k] = row * 384 + q * 96 + c * 8;
+            grow[k] = row;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + 256 + (p * 32 + r) * 4);
+            const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
+            const float rstd = 1.0f / sqrtf(var + eps);
+            half4 hi[3][4], lo[3][4];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(par + feat);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(par + 384 + feat);
+                    f32x4 y;
 #pragma unroll
-                    for (int p = 0; p < PT; ++p) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(stage + (p * 32 + r) * LN_LD + feat);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = fmaf(acc[i][t0 + p][4 * g + j], WT_UNSCALE, b[j]) + xv[j];
-                            acc[i][t0 + p][4 * g + j] = v;
-                            part[p] = part[p] + v;
-                        }
-                    }
+                    for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][p][4 * g + j] * rstd, gm[j], bt[j]);
+                    split_act4(y, hi[i][g], lo[i][g]);
                 }
+            u32x4 oh[6], ol[6];
+            ICREC_STAMP(0, 37 + 3 * p); ICREC_STAMP(4, 37 + 3 * p);
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                part[p] = part[p] + __shfl_xor(part[p], 32, 64);  // Pq (a + b == b + a exactly: both halves hold the same bits)
-                if (h == 0) red[(p * 32 + r) * 4 + q] = part[p];
-            }
-        }
-        ICREC_STAMP(0, sb + 3); ICREC_STAMP(4, sb + 3);
-        sync();
-        if (active) {
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + (p * 32 + r) * 4);
-                const float mean = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
-                float sq = 0.0f;
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = hi[i][g];
+            lds_order();
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 6; ++k) oh[k] = *reinterpret_cast<const u32x4*>(tile + lpos[k]);
+            lds_order();
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float d = acc[i][t0 + p][e] - mean;
-                        acc[i][t0 + p][e] = d;
-                        sq = fmaf(d, d, sq);
-                    }
-                sq = sq + __shfl_xor(sq, 32, 64);
-                if (h == 0) red[ROWS * 4 + (p * 32 + r) * 4 + q] = sq;
-            }
-        }
-        ICREC_STAMP(0, sb + 4); ICREC_STAMP(4, sb + 4);
-        sync();
-        if (active) {
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + ROWS * 4 + (p * 32 + r) * 4);
-                const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
-                const float rstd = 1.0f / sqrtf(var + eps);
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = lo[i][g];
+            lds_order();
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 6; ++k) ol[k] = *reinterpret_cast<const u32x4*>(tile + lpos[k]);
+            lds_order();
+            const int64_t t0 = m0 + p * 32;
+            ICREC_STAMP(0, 38 + 3 * p); ICREC_STAMP(4, 38 + 3 * p);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + feat);
-                        const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + feat);
-                        f32x4 y;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][t0 + p][4 * g + j] * rstd, gm[j], bt[j]);
-                        *reinterpret_cast<f32x4*>(stage + (p * 32 + r) * LN_LD + feat) = y;
-                    }
-            }
-        }
-        ICREC_STAMP(0, sb + 5); ICREC_STAMP(4, sb + 5);
-        sync();
-        {   // normalised rows out, flat: fp32 x (16 B per thread) and its two f16 planes (8 B each)
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int f = tid + NT * k, row = f / 96, c = f - row * 96;
-                const int64_t g = row0 + row;
-                if (g < T) {
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
-                    half4 hi, lo;
-                    split_act4(y, hi, lo);
-                    *reinterpret_cast<f32x4*>(x + g * 384 + c * 4) = y;
-                    *reinterpret_cast<half4*>(xh + g * 384 + c * 4) = hi;
-                    *reinterpret_cast<half4*>(xl + g * 384 + c * 4) = lo;
+            for (int k = 0; k < 6; ++k)
+                if (t0 + grow[k] < T) {
+                    *reinterpret_cast<u32x4*>(xh + t0 * 384 + gpos[k]) = oh[k];
+                    *reinterpret_cast<u32x4*>(xl + t0 * 384 + gpos[k]) = ol[k];
                 }
-            }
+            ICREC_STAMP(0, 39 + 3 * p); ICREC_STAMP(4, 39 + 3 * p);
         }
-        ICREC_STAMP(0, sb + 6); ICREC_STAMP(4, sb + 6);
-        if (t0 + PT < 2) sync();  // the stage is rewritten by the next pass
     }
+    ICREC_STAMP(0, 36); ICREC_STAMP(4, 36);
 }
 
-// The unfused form of the same LayerNorm (small batches; ICREC_FUSE=0): x <- LN(a + x) with the reduction order of
-// wt_ln_staged.  8 threads per token: thread (q, h) sums its 48 values in (i, g, j) order, the 8 partials are
-// combined by shuffles in the fixed tree.  `a` already holds dense(.) + bias.
-__global__ __launch_bounds__(256) void add_ln_wt_kernel(const float* __restrict__ a, float* __restrict__ x, int T,
-                                                        const float* __restrict__ gam, const float* __restrict__ bet,
-                                                        float eps, _Float16* __restrict__ xh,
-                                                        _Float16* __restrict__ xl) {
+// The unfused form of the same LayerNorm (small batches; ICREC_FUSE=0): planes(x) <- LN(a), `a` = dense(.) + bias +
+// residual as the EPI 2 GEMM wrote it.  8 threads per token: thread (q, h) sums its 48 values in (i, g, j) order,
+// the 8 partials are combined by shuffles in the fixed tree of wt_ln_out.
+__global__ __launch_bounds__(256) void ln_wt_kernel(const float* __restrict__ a, int T, const float* __restrict__ gam,
+                                                    const float* __restrict__ bet, float eps,
+                                                    _Float16* __restrict__ xh, _Float16* __restrict__ xl) {
     const int tid = threadIdx.x, slot = tid & 7, q = slot >> 1, h = slot & 1;
     int64_t tok = (int64_t)blockIdx.x * 32 + (tid >> 3);
     const bool ok = tok < T;
@@ -449,14 +432,9 @@ __global__ __launch_bounds__(256) void add_ln_wt_kernel(const float* __restrict_
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int64_t at = tok * 384 + q * 96 + i * 32 + 8 * g + 4 * h;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a + at);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + at);
+            v[i][g] = *reinterpret_cast<const f32x4*>(a + tok * 384 + q * 96 + i * 32 + 8 * g + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[i][g][j] = av[j] + xv[j];
-                part = part + v[i][g][j];
-            }
+            for (int j = 0; j < 4; ++j) part = part + v[i][g][j];
         }
     const int base = (tid & 63) & ~7;  // first lane of this token's 8 threads
     auto tree = [&](float p) {  // ((P0 + P1) + P2) + P3 with Pq = part(q,0) + part(q,1); every lane gets the same bits
@@ -492,11 +470,114 @@ __global__ __launch_bounds__(256) void add_ln_wt_kernel(const float* __restrict_
             for (int j = 0; j < 4; ++j) y[j] = fmaf(v[i][g][j] * rstd, gm[j], bt[j]);
             split_act4(y, hi, lo);
             if (ok) {
-                *reinterpret_cast<f32x4*>(x + tok * 384 + feat) = y;
                 *reinterpret_cast<half4*>(xh + tok * 384 + feat) = hi;
                 *reinterpret_cast<half4*>(xl + tok * 384 + feat) = lo;
             }
         }
+}
+
+constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 16-B accesses of consecutive tokens hit distinct banks)
+
+// ---------------------------------------------------------------- f16x3 linear layers (wt_gemm.h)
+// out^T = W . X^T with the weights streamed straight from L2 into registers (packed fragment order) and the
+// token slab staged through LDS.  Block = 4 waves; wave q owns NTW 32-feature tiles x TTW 32-token tiles.
+//   EPI 0: out fp32 [T, N] = acc * 2^-14 + bias           (QKV)
+//   EPI 1: erf-GELU (tf:336), result as f16 hi/lo planes   (FFN-up of small batches)
+//   EPI 2: accumulators start from residual + bias (planes rh / rl, row stride N), out fp32 = acc * 2^-14: the
+//          LayerNorm input of attention-out / FFN-down for small batches (ln_wt_kernel follows)
+// Each lane holds 4 consecutive features of one token per register group: 16-B (fp32) / 8-B (planes) stores.
+template <int NTW, int TTW, int D, int EPI>
+__global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __restrict__ Xh,
+                                                           const _Float16* __restrict__ Xl, int T, int K,
+                                                           const _Float16* __restrict__ Wp, int N,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           _Float16* __restrict__ oh, _Float16* __restrict__ ol,
+                                                           int n_blocks_n) {
+    constexpr bool STAGED = (NTW == 3 && TTW == 2 && EPI != 1);  // batch form: results leave through an LDS stage, coalesced
+    constexpr int SM = (STAGED && 32 * LN_LD * 4 > XRing<TTW>::BYTES) ? 32 * LN_LD * 4 : XRing<TTW>::BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM];
+    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    // the n_blocks_n workgroups that read the same token rows get consecutive logical ids = the same XCD = one L2
+    // (PMC: without the remap the QKV launch fetched its activations three times, 930 MB instead of ~330 MB)
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
+    const int64_t m0 = (int64_t)mt * (32 * TTW);
+    const int nt0 = (nb * 4 + q) * NTW;
+    f32x16 acc[NTW][TTW];
+    if constexpr (EPI == 2) {  // oh / ol carry the residual planes here
+        if constexpr (NTW == 3 && TTW == 2) {
+            wt_res_init_global(acc, q, bias + nb * 384, oh + nb * 384, ol + nb * 384, m0, T, smem + q * LNT_TILE);
+            __syncthreads();
+        } else {
+            static_assert(NTW == 1 && TTW == 1, "residual init: 3 x 2 or 1 x 1 wave tiles");
+            wt_res_init_direct(acc, nt0, bias, oh, ol, N, m0, T);
+        }
+    }
+    wt_kloop<NTW, TTW, D, EPI != 2>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);
+    if constexpr (STAGED) {
+        // [384 features x 32 tokens] per pass -> stage[token][feature] (16-B LDS writes), then 16-B chunks in flat
+        // order: every wave store instruction writes 1 KB of at most two output rows.  (Storing 16 B per lane with
+        // the lanes 4,608 B apart took as long as the whole K loop: 32k of 69k cycles per block by in-kernel stamps.)
+        float* const stage = reinterpret_cast<float*>(smem);
+        const int n0 = nb * 384;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int fl = q * 96 + i * 32 + 8 * g + 4 * h;
+                    f32x4 b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (EPI == 0) b = *reinterpret_cast<const f32x4*>(bias + n0 + fl);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = EPI == 2 ? acc[i][tt][4 * g + j] * WT_UNSCALE : fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
+                    *reinterpret_cast<f32x4*>(stage + r * LN_LD + fl) = v;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int f = threadIdx.x + 256 * k, row = f / 96, c = f - row * 96;
+                const int64_t tok = m0 + tt * 32 + row;
+                if (tok < T)
+                    *reinterpret_cast<f32x4*>(out + tok * N + n0 + c * 4) = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
+            }
+            if (tt == 0) __syncthreads();
+        }
+        ICREC_STAMP(0, 30);
+        return;
+    }
+
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int feat = (nt0 + i) * 32 + 8 * g + 4 * h;
+            f32x4 b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (EPI != 2) b = *reinterpret_cast<const f32x4*>(bias + feat);
+#pragma unroll
+            for (int tt = 0; tt < TTW; ++tt) {
+                const int64_t tok = m0 + tt * 32 + r;
+                if (tok < T) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = EPI == 2 ? acc[i][tt][4 * g + j] * WT_UNSCALE : fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
+                    if (EPI == 1) {
+                        half4 hi, lo;
+                        half2w a, b, c, d;
+                        split_pair_prescaled(gelu16_wt(v[0]), gelu16_wt(v[1]), a, b);
+                        split_pair_prescaled(gelu16_wt(v[2]), gelu16_wt(v[3]), c, d);
+                        hi = half4{a[0], a[1], c[0], c[1]};
+                        lo = half4{b[0], b[1], d[0], d[1]};
+                        *reinterpret_cast<half4*>(oh + tok * N + feat) = hi;
+                        *reinterpret_cast<half4*>(ol + tok * N + feat) = lo;
+                    } else {
+                        *reinterpret_cast<f32x4*>(out + tok * N + feat) = v;
+                    }
+                }
+            }
+        }
+    ICREC_STAMP(0, 30);
 }
 
 // Attention-output projection + residual + LayerNorm in one kernel (large batches): block = 64 tokens x all 384
@@ -505,17 +586,19 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __restrict__ Ah,
                                                               const _Float16* __restrict__ Al, int T, int K,
                                                               const _Float16* __restrict__ Wp,
-                                                              const float* __restrict__ bias, float* __restrict__ x,
+                                                              const float* __restrict__ bias,
                                                               _Float16* __restrict__ xh, _Float16* __restrict__ xl,
                                                               const float* __restrict__ gam,
                                                               const float* __restrict__ bet, float eps) {
-    constexpr int SM = XRing<2>::BYTES > LnStage<1>::BYTES ? XRing<2>::BYTES : LnStage<1>::BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SM];
+    static_assert(XRing<2>::BYTES >= LNT_BYTES, "the slab ring doubles as the LayerNorm scratch");
+    __shared__ __attribute__((aligned(16))) char smem[XRing<2>::BYTES];
     const int q = wave_uniform(threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     f32x16 acc[3][2];
-    wt_kloop<3, 2, D>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
-    wt_ln_staged<1, 256>(acc, true, q, bias, x, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); });
+    wt_res_init_global(acc, q, bias, xh, xl, m0, T, smem + LNT_RED + q * LNT_TILE);
+    __syncthreads();  // the private tiles become the slab ring
+    wt_kloop<3, 2, D, false>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
+    wt_ln_out(acc, true, q, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); });
     ICREC_STAMP(0, 30);
 }
 
@@ -546,15 +629,14 @@ constexpr int FFN2_HPLANE = 64 * 256;                    // [64 tokens][128 k] h
 constexpr int FFN2_HBUF = 2 * FFN2_HPLANE;               // hi, lo
 constexpr int FFN2_LDS = FFN2_X_BYTES + 2 * FFN2_HBUF;   // 163,840 B = the whole LDS of a CU
 static_assert(FFN2_LDS == 160 * 1024, "fused FFN LDS budget");
-static_assert(LnStage<2>::BYTES <= FFN2_LDS, "LayerNorm stage");
 
 __device__ __forceinline__ void bar_lds() {  // LDS hand-off barrier that leaves global loads in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int VAR>
-__global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ x, _Float16* __restrict__ xh,
-                                                            _Float16* __restrict__ xl, int T, int I,
+__global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict__ xh, _Float16* __restrict__ xl,
+                                                            int T, int I,
                                                             const _Float16* __restrict__ W1p,
                                                             const float* __restrict__ b1,
                                                             const _Float16* __restrict__ W2p,
@@ -718,12 +800,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
         bar_lds();  // B(NC): H[NC - 1]
         ICREC_STAMP(0, 26);
     } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) Y[i][tt][e] = 0.0f;
         const _Float16* w2p[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2);
@@ -735,6 +811,23 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
         for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
         __syncthreads();  // X resident (matches the producers' first barrier)
         ICREC_STAMP(4, 1);
+        // Y starts from the residual + bias: the block's own planes, already in LDS (wt_res_init_*: same value)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = q * 12 + i * 4 + g;  // 16-B chunk of the token row holding features q*96 + i*32 + 8g .. +7
+                const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + q * 96 + i * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int tok = tt * 32 + r;
+                    const int pos = tok * 768 + (((c & ~15) | ((c ^ tok) & 15)) << 4) + 8 * h;
+                    const half4 a = *reinterpret_cast<const half4*>(Xs + pos);
+                    const half4 d = *reinterpret_cast<const half4*>(Xs + FFN2_XPLANE + pos);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Y[i][tt][4 * g + j] = res_init_val(a[j], d[j], b[j]);
+                }
+            }
         bar_lds();        // B1: H[0] is ready
         for (int c = 0; c < NC; ++c) {
             ICREC_STAMP(4, 2 + 2 * c);
@@ -770,9 +863,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(float* __restrict__ 
     }
     ICREC_STAMP(0, 27);
     ICREC_STAMP(4, 27);
-    // ---- residual + LayerNorm on the consumers' accumulators (the producers only join the two barriers)
-    __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm stage
-    wt_ln_staged<2, 512>(Y, !producer, q, b2, x, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); });
+    // ---- LayerNorm on the consumers' accumulators (the producers only join the two barriers)
+    __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm scratch
+    wt_ln_out(Y, !producer, q, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); });
     ICREC_STAMP(0, 30);
     ICREC_STAMP(4, 30);
 }
@@ -1187,9 +1280,12 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
 // sentence_transformers Pooling(mean): sum_t h_t / clamp(count, 1e-9); then n_norm times
 // x / max(|x|_2, 1e-12) (Normalize module, normalize_embeddings=True).  One workgroup of
 // H threads per sequence; norm in oracle order by wave 0.
-template <int H>
-__global__ __launch_bounds__(H) void pool_norm_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+template <int H, bool PLANES>
+__global__ __launch_bounds__(H) void pool_norm_kernel(const float* __restrict__ x, const _Float16* __restrict__ xh,
+                                                      const _Float16* __restrict__ xl, const int32_t* __restrict__ cu,
                                                       int n_norm, float* __restrict__ out) {
+    // PLANES (f16x3 mode): the hidden state is its two planes, h_t = (float(hi) + float(lo)) / 16 exactly
+    auto at = [&](size_t idx) { return PLANES ? ((float)xh[idx] + (float)xl[idx]) * (1.0f / WT_SA) : x[idx]; };
     __shared__ float v[H];
     __shared__ float den_s;
     const int s = blockIdx.x, i = threadIdx.x;
@@ -1199,11 +1295,11 @@ __global__ __launch_bounds__(H) void pool_norm_kernel(const float* __restrict__ 
     for (; t + 8 <= t1; t += 8) {  // 8 independent loads in flight, summed in ascending token order
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(t + u) * H + i];
+        for (int u = 0; u < 8; ++u) v[u] = at((size_t)(t + u) * H + i);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = acc + v[u];
     }
-    for (; t < t1; ++t) acc = acc + x[(size_t)t * H + i];
+    for (; t < t1; ++t) acc = acc + at((size_t)t * H + i);
     float cnt = (float)(t1 - t0);
     cnt = cnt < 1e-9f ? 1e-9f : cnt;
     float val = acc / cnt;
@@ -1494,30 +1590,29 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                                     qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
             };
             auto post_stage = [&](int r0, int Tn) -> int {
-                float* const xr = x + (size_t)r0 * H;
                 float* const t1r = t1 + (size_t)r0 * H;
                 _Float16 *const xhr = xh + (size_t)r0 * H, *const xlr = xl + (size_t)r0 * H;
                 const _Float16 *const chr = ch + (size_t)r0 * H, *const clr = cl + (size_t)r0 * H;
                 if (Tn > X3_SMALL_M && fuse) {
                     // attention-out + residual + LN, then the whole FFN block + residual + LN: two kernels per half layer
                     hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((Tn + 63) / 64), dim3(256), 0, st, chr, clr, Tn, H,
-                                       L.Wo_p, L.bo, xr, xhr, xlr, L.g1, L.b1n, c.ln_eps);
+                                       L.Wo_p, L.bo, xhr, xlr, L.g1, L.b1n, c.ln_eps);
                     ScopedTimer tm(T_FFN_UP, st);
                     auto kern = ffn_fused2_kernel<0>;
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
-                    hipLaunchKernelGGL(kern, dim3((Tn + 63) / 64), dim3(512), FFN2_LDS, st, xr, xhr, xlr, Tn, I, L.W1_p,
+                    hipLaunchKernelGGL(kern, dim3((Tn + 63) / 64), dim3(512), FFN2_LDS, st, xhr, xlr, Tn, I, L.W1_p,
                                        L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
                 } else {
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
-                    launch_wt_linear<0>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, nullptr, nullptr, st);
-                    hipLaunchKernelGGL(add_ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, xr, Tn, L.g1, L.b1n,
+                    launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes
+                    hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, Tn, L.g1, L.b1n,
                                        c.ln_eps, xhr, xlr);
                     {
                         ScopedTimer tm(Tn > X3_SMALL_M ? T_FFN_UP : T_NSLOTS - 1, st);
                         launch_wt_linear<1>(xhr, xlr, Tn, H, L.W1_p, I, L.b1, nullptr, hhr, hlr, st);
                     }
-                    launch_wt_linear<0>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, nullptr, nullptr, st);
-                    hipLaunchKernelGGL(add_ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, xr, Tn, L.g2, L.b2n,
+                    launch_wt_linear<2>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, xhr, xlr, st);
+                    hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, Tn, L.g2, L.b2n,
                                        c.ln_eps, xhr, xlr);
                 }
                 return ICREC_OK;
@@ -1543,7 +1638,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                                c.ln_eps, xh, xl);
         }
     }
-    hipLaunchKernelGGL(pool_norm_kernel<HID>, dim3(n_seqs), dim3(HID), 0, st, x, cu_dev, c.n_normalize, out_dev);
+    if (x3) hipLaunchKernelGGL((pool_norm_kernel<HID, true>), dim3(n_seqs), dim3(HID), 0, st, x, xh, xl, cu_dev, c.n_normalize, out_dev);
+    else hipLaunchKernelGGL((pool_norm_kernel<HID, false>), dim3(n_seqs), dim3(HID), 0, st, x, xh, xl, cu_dev, c.n_normalize, out_dev);
     ICREC_HIP(hipGetLastError());
     return ICREC_OK;
 }

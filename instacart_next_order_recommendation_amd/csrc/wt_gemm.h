@@ -169,7 +169,7 @@ __device__ unsigned long long g_stamps[1 << 22];
 // acc[i][tt] = sum_k W[(nt0 + i) tile][k] . X[m0 + tt tile][k], K in slabs of 64 (4 k-steps); weight fragments
 // D k-steps ahead in registers (D divides 4), the next activation slab one slab ahead in registers, two LDS
 // stages, one barrier per slab.  `smem`: XRing<TTW>::BYTES.
-template <int NTW, int TTW, int D>
+template <int NTW, int TTW, int D, bool ZERO = true>
 __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16* __restrict__ Wp, int nt0, int K,
                                          const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, int64_t m0,
                                          int64_t T, char* smem) {
@@ -181,12 +181,14 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
     const _Float16* wp[NTW];  // wave-uniform (nt0 must be)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) wp[i] = Wp + wt_frag_off(nt0 + i, 0, KS);
+    if (ZERO) {  // !ZERO: the caller has put the residual + bias into the accumulators (wt_res_init_*)
 #pragma unroll
-    for (int i = 0; i < NTW; ++i)
+        for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int tt = 0; tt < TTW; ++tt)
+            for (int tt = 0; tt < TTW; ++tt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][tt][e] = 0.0f;
+                for (int e = 0; e < 16; ++e) acc[i][tt][e] = 0.0f;
+    }
     half8 wh[D][NTW], wl[D][NTW];
     // activation slabs: TWO in flight in registers (slab s+1 is written to LDS at the end of slab s, slab s+2 was
     // requested a whole slab earlier) - with one, every slab boundary waited for an HBM round trip (stamps: the first
