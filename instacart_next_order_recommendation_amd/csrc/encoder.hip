@@ -298,26 +298,33 @@ __device__ __forceinline__ void wt_res_init_direct(f32x16 (&acc)[1][1], int nt0,
     }
 }
 
+// this thread's 16 bytes of the [gamma | beta] table wt_ln_out keeps in LDS (threads 0 .. 191 of the callers)
+__device__ __forceinline__ f32x4 wt_ln_par_load(const float* __restrict__ gam, const float* __restrict__ bet, int ptid) {
+    const int t = ptid < 192 ? ptid : 0;
+    return *reinterpret_cast<const f32x4*>((t < 96 ? gam : bet - 384) + 4 * t);
+}
+
 // LayerNorm of a block's accumulators (acc = residual + bias + dense, in units of 2^-14) -> the two planes of x.
 // NT threads call; `active` = this wave holds accumulators (wave-uniform), `sync` = the workgroup barrier.
-// lds: LNT_BYTES.  At least 192 threads must call.
+// lds: LNT_BYTES.  ptid: index of the thread among the callers (0 .. 191 must be present).
 template <class Sync>
 __device__ __forceinline__ void wt_ln_out(f32x16 (&acc)[3][2], bool active, int q, _Float16* __restrict__ xh,
                                           _Float16* __restrict__ xl, int64_t m0, int64_t T,
                                           const float* __restrict__ gam, const float* __restrict__ bet, float eps,
-                                          char* lds, Sync sync) {
+                                          char* lds, Sync sync, int ptid, int salt = 0,
+                                          const f32x4* par_pre = nullptr) {
+    // salt: 0, opaque to the compiler when the call sits in a loop - otherwise the per-lane addresses below are
+    // hoisted out of the loop and held (or spilled) across it
     float* const red = reinterpret_cast<float*>(lds);
     char* const tile = lds + LNT_RED + q * LNT_TILE;
     float* const par = reinterpret_cast<float*>(lds + LNT_RED + 4 * LNT_TILE);
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int lane = (threadIdx.x & 63) + salt, r = lane & 31, h = lane >> 5;
     ICREC_STAMP(0, 32); ICREC_STAMP(4, 32);
     // gamma / beta -> LDS (visible after the first barrier): each lane needs the 48 values of its half of the wave's 96
     // features, the same in every lane of the half - as vector loads that is 96 x 1 KB through the texture path per wave
     // for 768 distinct bytes (measured: the normalise + write-out phase was bound by them)
-    if (threadIdx.x < 192) {
-        const int t = threadIdx.x;
-        *reinterpret_cast<f32x4*>(par + 4 * t) = *reinterpret_cast<const f32x4*>((t < 96 ? gam : bet - 384) + 4 * t);
-    }
+    // par_pre: the caller loaded this thread's 16 bytes earlier (wt_ln_par_load), off the critical path
+    if (ptid < 192) *reinterpret_cast<f32x4*>(par + 4 * ptid) = par_pre ? *par_pre : wt_ln_par_load(gam, bet, ptid);
     if (active) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -358,20 +365,20 @@ __device__ __forceinline__ void wt_ln_out(f32x16 (&acc)[3][2], bool active, int 
     sync();
     ICREC_STAMP(0, 35); ICREC_STAMP(4, 35);
     if (active) {
-        int lpos[6], gpos[6], grow[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int f = lane + 64 * k, row = f / 12, c = f - row * 12;
-            lpos[k] = row * LNT_ROW + c * 16;
-            gpos[k] = row * 384 + q * 96 + c * 8;
-            grow[k] = row;
-        }
+        // chunk k of this lane in the flat [32 rows][12 x 16 B] view of a tile: row = f / 12, c = f % 12, f = lane + 64 k
+        auto flat = [&](int k, int& row, int& c) {
+            const int f = lane + 64 * k;
+            row = (f * 43691) >> 19;  // f / 12 for f < 384
+            c = f - row * 12;
+        };
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + 256 + (p * 32 + r) * 4);
             const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
             const float rstd = 1.0f / sqrtf(var + eps);
-            half4 hi[3][4], lo[3][4];
+            const int64_t t0 = m0 + p * 32;
+            half4 lo[3][4];
+            // the hi plane goes straight into the tile; lo waits in registers for its turn
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -382,34 +389,45 @@ __device__ __forceinline__ void wt_ln_out(f32x16 (&acc)[3][2], bool active, int 
                     f32x4 y;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][p][4 * g + j] * rstd, gm[j], bt[j]);
-                    split_act4(y, hi[i][g], lo[i][g]);
+                    half4 hi;
+                    split_act4(y, hi, lo[i][g]);
+                    *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = hi;
                 }
-            u32x4 oh[6], ol[6];
             ICREC_STAMP(0, 37 + 3 * p); ICREC_STAMP(4, 37 + 3 * p);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = hi[i][g];
             lds_order();
+            u32x4 o[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) oh[k] = *reinterpret_cast<const u32x4*>(tile + lpos[k]);
+            for (int k = 0; k < 6; ++k) {
+                int row, c;
+                flat(k, row, c);
+                o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + c * 16);
+            }
             lds_order();
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = lo[i][g];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {  // the hi rows leave while the lo tile is written
+                int row, c;
+                flat(k, row, c);
+                if (t0 + row < T) *reinterpret_cast<u32x4*>(xh + (t0 + row) * 384 + q * 96 + c * 8) = o[k];
+            }
             lds_order();
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ol[k] = *reinterpret_cast<const u32x4*>(tile + lpos[k]);
+            for (int k = 0; k < 6; ++k) {
+                int row, c;
+                flat(k, row, c);
+                o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + c * 16);
+            }
             lds_order();
-            const int64_t t0 = m0 + p * 32;
             ICREC_STAMP(0, 38 + 3 * p); ICREC_STAMP(4, 38 + 3 * p);
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (t0 + grow[k] < T) {
-                    *reinterpret_cast<u32x4*>(xh + t0 * 384 + gpos[k]) = oh[k];
-                    *reinterpret_cast<u32x4*>(xl + t0 * 384 + gpos[k]) = ol[k];
-                }
+            for (int k = 0; k < 6; ++k) {
+                int row, c;
+                flat(k, row, c);
+                if (t0 + row < T) *reinterpret_cast<u32x4*>(xl + (t0 + row) * 384 + q * 96 + c * 8) = o[k];
+            }
             ICREC_STAMP(0, 39 + 3 * p); ICREC_STAMP(4, 39 + 3 * p);
         }
     }
@@ -598,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __
     wt_res_init_global(acc, q, bias, xh, xl, m0, T, smem + LNT_RED + q * LNT_TILE);
     __syncthreads();  // the private tiles become the slab ring
     wt_kloop<3, 2, D, false>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
-    wt_ln_out(acc, true, q, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); });
+    wt_ln_out(acc, true, q, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); }, threadIdx.x);
     ICREC_STAMP(0, 30);
 }
 
@@ -865,9 +883,345 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
     ICREC_STAMP(4, 27);
     // ---- LayerNorm on the consumers' accumulators (the producers only join the two barriers)
     __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm scratch
-    wt_ln_out(Y, !producer, q, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); });
+    wt_ln_out(Y, !producer, q, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, threadIdx.x);
     ICREC_STAMP(0, 30);
     ICREC_STAMP(4, 30);
+}
+
+// Persistent form of the same computation: one workgroup per CU walks blocks j = blockIdx.x, + gridDim.x, ... and the
+// block boundary is software-pipelined away.  Time is cut into epochs (one workgroup barrier each); in epoch (j, k)
+//   producers   k = 0: P1(0)   k = 1..11: P1(k) + G(k-1)   k = 12 ("drain"): G(11), and block j+1's planes -> LDS
+//   consumers   k = 0: P2(11) of block j-1   k = 1: LayerNorm + write-out of block j-1, then Y0 of block j
+//               k = 2..12: P2(k-2)
+// so the LayerNorm epilogue of a block runs in the slot where the consumers would wait for the first H chunk of the
+// next one, under the producers' MFMAs; its scratch is the H buffer that is idle in that epoch (H[1]: P2(11) has
+// consumed it, G(1) is written an epoch later), its two internal barriers are matched by two extra barriers inside
+// the producers' iteration 1.  The next block's activation planes travel global -> registers -> LDS inside the
+// drain epoch (the producers' MFMA-free epoch: weight ring, S and the fragment registers are idle), into the X
+// region that P1(11) has just left.  Arithmetic and order per output are those of ffn_fused2_kernel.
+// VAR: timing experiments of tools/ffn_bench.hip (the product uses 0).
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void ffn_fused3_kernel(_Float16* __restrict__ xh, _Float16* __restrict__ xl,
+                                                            int T, int I, const _Float16* __restrict__ W1p,
+                                                            const float* __restrict__ b1,
+                                                            const _Float16* __restrict__ W2p,
+                                                            const float* __restrict__ b2,
+                                                            const float* __restrict__ gam,
+                                                            const float* __restrict__ bet, float eps) {
+    constexpr int KS1 = 24;
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    char* const Xs = smem3;
+    char* const Hs = smem3 + FFN2_X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), q = wave & 3, r = lane & 31, h = lane >> 5;
+    const bool producer = wave < 4;
+    const int G = gridDim.x, nblk = (T + 63) / 64;
+    const int J = (nblk - (int)blockIdx.x + G - 1) / G;  // blocks of this workgroup (host: gridDim.x <= nblk)
+    const int NC = I / FFN_IC, KS2 = I / 16;
+    auto block_m0 = [&](int j) { return (int64_t)(j * G + (int)blockIdx.x) * 64; };
+
+    // ---- stagger: the workgroups of a launch would otherwise walk their blocks in lockstep, and every block boundary
+    // (64 x 768 B of planes in, the same out) would hit HBM from all CUs in the same few microseconds.  Eight phases,
+    // ~1.5k cycles apart (about one epoch in total: the weight chunks the CUs of an XCD share stay the same ones).
+    for (int ph = ((int)blockIdx.x >> 3) & 7; ph > 0; --ph) __builtin_amdgcn_s_sleep(23);
+    // ---- the first block's activation planes -> LDS (16-B chunk c of token row t at sub-row c >> 4, slot (c ^ t) & 15)
+    {
+        const int64_t m0 = block_m0(0);
+        u32x4 vh[6], vl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            int64_t g = m0 + row;
+            g = g < T ? g : (int64_t)T - 1;
+            vh[i] = *reinterpret_cast<const u32x4*>(xh + g * 384 + c * 8);
+            vl[i] = *reinterpret_cast<const u32x4*>(xl + g * 384 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
+            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
+            *reinterpret_cast<u32x4*>(Xs + FFN2_XPLANE + pos) = vl[i];
+        }
+    }
+
+    const unsigned lo8 = lane * 8;
+    if (producer) {
+        int xb[8][2];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int tok = tt * 32 + r;
+                xb[m][tt] = tok * 768 + (((2 * m) ^ h ^ (tok & 15)) << 4);
+            }
+        half8 wh[8][1], wl[8][1];
+        {
+            const _Float16* const wp0[1] = {W1p + wt_frag_off(q, 0, KS1)};
+#pragma unroll
+            for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
+        }
+        __syncthreads();  // X(0) resident
+        f32x16 S[1][2], Sp[1][2];
+        f32x4 bias[4], biasp[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Sp[0][tt][e] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) biasp[g] = bias[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // one epoch of the producers: P1(c) if MMA, the GELU of the previous chunk spread over the k-steps if GEL;
+        // sync2: join the two internal barriers of the consumers' LayerNorm; the drain (!MMA) also moves the next
+        // block's planes (rows m0n ..) into LDS when there is one
+        // W1j / b1j: the weight and bias pointers, re-defined (opaquely) once per block - the same addresses are read
+        // for every block, and as loop-invariant loads the compiler would hoist a whole iteration's weight stream
+        // out of the block loop and spill it
+        const _Float16* W1j = W1p;
+        const float* b1j = b1;
+        auto iteration = [&](int c, auto mma_tag, auto gel_tag, bool sync2, int64_t m0n, bool has_next) {
+            constexpr bool MMA = decltype(mma_tag)::value, GEL = decltype(gel_tag)::value;
+            const _Float16* const wp1[1] = {W1j + wt_frag_off((MMA ? c : 0) * 4 + q, 0, KS1)};
+            const _Float16* const wpn[1] = {W1j + wt_frag_off((MMA && c + 1 < NC ? c + 1 : 0) * 4 + q, 0, KS1)};
+            if (MMA) {  // biases before the k-loop: a load issued behind the weight ring would wait for the whole ring
+                const float* bp = b1j + c * FFN_IC + q * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+            }
+            // drain: the next block's planes in four quarters of 6 chunks per producer thread (hi rows 0-31, hi rows 32-63,
+            // lo likewise), each requested 6 k-steps before it is written to LDS
+            u32x4 xv[6];
+            int tids = tid;  // opaque copy: keeps the drain's address arithmetic inside the drain (not hoisted across the block loop)
+            if (!MMA) asm volatile("" : "+v"(tids));
+            auto x_next_load = [&](int quarter) {
+                const _Float16* plane = quarter < 2 ? xh : xl;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int id = tids + 256 * (i + 6 * (quarter & 1)), row = id / 48, cc = id - row * 48;
+                    int64_t g = m0n + row;
+                    g = g < T ? g : (int64_t)T - 1;
+                    xv[i] = *reinterpret_cast<const u32x4*>(plane + g * 384 + cc * 8);
+                }
+            };
+            auto x_next_store = [&](int quarter) {
+                char* dst = Xs + (quarter < 2 ? 0 : FFN2_XPLANE);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int id = tids + 256 * (i + 6 * (quarter & 1)), row = id / 48, cc = id - row * 48;
+                    *reinterpret_cast<u32x4*>(dst + row * 768 + (((cc & ~15) | ((cc ^ row) & 15)) << 4)) = xv[i];
+                }
+            };
+            if (!MMA && has_next) x_next_load(0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+            char* const Hb = Hs + ((c + 1) & 1) * FFN2_HBUF;  // H[(c - 1) & 1]
+            half8 fh[2][2], fl[2][2];
+            half4 ghi, glo;
+            if (MMA) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb[0][tt]);
+                    fl[0][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + xb[0][tt]);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                if (MMA && GEL && (ks == 8 || ks == 16)) {
+                    if (sync2) bar_lds();
+                }
+                if (MMA) {
+                    if (ks + 1 < KS1) {
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const int pos = xb[(ks + 1) & 7][tt] + ((ks + 1) >> 3) * 256;
+                            fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
+                            fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
+                        }
+                    }
+                    wt_mma<1, 2>(S, wh[ks & 7], wl[ks & 7], fh[ks & 1], fl[ks & 1]);
+                    if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
+                    else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
+                }
+                if (GEL && ks % 3 != 2) {
+                    const int u = ks - ks / 3;
+                    {
+                        const int n = 2 * u, gi = n >> 2, j = n & 3, g = gi >> 1, tt = gi & 1;
+                        const float p0 = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
+                        const float p1 = fmaf(Sp[0][tt][4 * g + j + 1], WT_UNSCALE, biasp[g][j + 1]);
+                        half2w a, d;
+                        split_pair_prescaled(gelu16_wt(p0), gelu16_wt(p1), a, d);
+                        ghi[j] = a[0];
+                        ghi[j + 1] = a[1];
+                        glo[j] = d[0];
+                        glo[j + 1] = d[1];
+                    }
+                    if (u & 1) {
+                        const int gi = u >> 1, g = gi >> 1, tt = gi & 1;
+                        const int tok = tt * 32 + r;
+                        const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
+                        *reinterpret_cast<half4*>(Hb + pos) = ghi;
+                        *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = glo;
+                    }
+                    if (MMA) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                        }
+                    }
+                }
+                if (!MMA && (ks == 5 || ks == 11 || ks == 17) && has_next) {
+                    x_next_store(ks / 6);
+                    x_next_load(ks / 6 + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!MMA && has_next) x_next_store(3);
+            if (MMA) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) Sp[0][tt] = S[0][tt];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) biasp[g] = bias[g];
+            }
+        };
+        if (VAR & 2) __builtin_amdgcn_s_setprio(2);
+        if (VAR & 64) __builtin_amdgcn_s_setprio(3);
+        for (int j = 0; j < J; ++j) {
+            {   // an opaque zero OFFSET (not an opaque pointer: that would turn the loads into flat_load, which count
+                // against lgkmcnt as well and serialise with the LDS fragment reads)
+                int zero = 0;
+                asm volatile("" : "+s"(zero));
+                W1j = W1p + zero;
+                b1j = b1 + zero;
+            }
+            if (j == 1) ICREC_STAMP(0, 0);
+            iteration(0, std::true_type{}, std::false_type{}, false, 0, false);
+            if (j == 1) ICREC_STAMP(0, 1);
+            bar_lds();
+            if (j == 1) ICREC_STAMP(0, 2);
+            for (int c = 1; c < NC; ++c) {
+                iteration(c, std::true_type{}, std::true_type{}, c == 1 && j > 0, 0, false);
+                if (j == 1) ICREC_STAMP(0, 1 + 2 * c);
+                bar_lds();
+                if (j == 1) ICREC_STAMP(0, 2 + 2 * c);
+            }
+            iteration(NC, std::false_type{}, std::true_type{}, false, block_m0(j + 1), j + 1 < J);
+            if (j == 1) ICREC_STAMP(0, 25);
+            bar_lds();
+            if (j == 1) ICREC_STAMP(0, 26);
+        }
+        bar_lds();  // epoch (J, 0): the consumers' last P2
+        bar_lds();  // the two barriers inside the last LayerNorm
+        bar_lds();
+    } else {
+        f32x16 Y[3][2];
+        const _Float16* w2p[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2);
+        int hb[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) hb[tt] = (tt * 32 + r) * 256 + ((h ^ (r & 15)) << 4);
+        half8 wh[4][3], wl[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
+        __syncthreads();  // X(0) resident (matches the producers' first barrier)
+        // LAST (chunk NC-1): no prefetch past the end - the ring is dead across the LayerNorm (which needs the
+        // registers) and is refilled for the next block right after it
+        auto P2 = [&](int c, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            const char* const Hb = Hs + (c & 1) * FFN2_HBUF;
+            half8 fh[2][2], fl[2][2];
+            int hbc[2] = {hb[0], hb[1]};  // opaque per chunk: the 14 derived fragment addresses are recomputed here (one
+                                          // v_xor each) instead of living in registers across the whole block loop
+            asm volatile("" : "+v"(hbc[0]), "+v"(hbc[1]));
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                fh[0][tt] = *reinterpret_cast<const half8*>(Hb + hbc[tt]);
+                fl[0][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + hbc[tt]);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                if (k2 + 1 < 8) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int pos = hbc[tt] ^ ((k2 + 1) << 5);
+                        fh[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + pos);
+                        fl[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + pos);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wt_mma<3, 2>(Y, wh[k2 & 3], wl[k2 & 3], fh[k2 & 1], fl[k2 & 1]);
+                if (VAR & 1) __builtin_amdgcn_s_sleep(4);
+                if (VAR & 4) __builtin_amdgcn_s_sleep(2);
+                if (!LAST || k2 < 4) w_load<3>(wh[k2 & 3], wl[k2 & 3], w2p, c * 8 + k2 + 4, lo8);
+                if (VAR & 8) __builtin_amdgcn_s_sleep(4);
+                if (VAR & 16) __builtin_amdgcn_s_sleep(2);
+                if (VAR & 32) __builtin_amdgcn_s_sleep(3);
+                if (VAR & 128) __builtin_amdgcn_s_sleep(6);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        const float *b2j = b2, *gamj = gam, *betj = bet;
+        for (int j = 0; j <= J; ++j) {
+            {   // per-block opaque re-definition of the weight / parameter pointers (see the producers)
+                int zero = 0;
+                asm volatile("" : "+s"(zero));
+                b2j = b2 + zero;
+                gamj = gam + zero;
+                betj = bet + zero;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w2p[i] = W2p + zero + wt_frag_off(q * 3 + i, 0, KS2);
+            }
+            if (j == 1) ICREC_STAMP(4, 0);
+            // requested now, used after the LayerNorm write-out: a load issued behind those stores would wait for them
+            const f32x4 parv = wt_ln_par_load(gamj, betj, tid - 256);
+            const f32x4 biasv = *reinterpret_cast<const f32x4*>(b2j + q * 96 + 4 * (lane < 24 ? lane : 0));
+            if (j > 0) P2(NC - 1, std::true_type{});
+            if (j == 1) ICREC_STAMP(4, 1);
+            bar_lds();  // end of epoch (j, 0)
+            if (j == 1) ICREC_STAMP(4, 2);
+            int salt = 0;  // see wt_ln_out
+            asm volatile("" : "+v"(salt));
+            if (j > 0)
+                wt_ln_out(Y, true, q, xh, xl, block_m0(j - 1), T, gamj, betj, eps, Hs + FFN2_HBUF, [] { bar_lds(); }, tid - 256, salt, &parv);
+            if (j == J) break;
+            if (j > 0) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
+            }
+            // Y starts from the residual + bias: the block's own planes, already in LDS (wt_res_init_*: same value); the
+            // wave's 96 bias values through its own (now idle) LayerNorm tile
+            float* const bq = reinterpret_cast<float*>(Hs + FFN2_HBUF + LNT_RED + q * LNT_TILE);
+            if (lane < 24) *reinterpret_cast<f32x4*>(bq + 4 * lane) = biasv;
+            lds_order();
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = q * 12 + i * 4 + g;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bq + i * 32 + 8 * g + 4 * h + salt);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int tok = tt * 32 + r + salt;
+                        const int pos = tok * 768 + (((c & ~15) | ((c ^ tok) & 15)) << 4) + 8 * h;
+                        const half4 a = *reinterpret_cast<const half4*>(Xs + pos);
+                        const half4 d = *reinterpret_cast<const half4*>(Xs + FFN2_XPLANE + pos);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) Y[i][tt][4 * g + jj] = res_init_val(a[jj], d[jj], b[jj]);
+                    }
+                }
+            if (j == 1) ICREC_STAMP(4, 3);
+            bar_lds();  // end of epoch (j, 1)
+            if (j == 1) ICREC_STAMP(4, 4);
+            for (int c = 0; c + 1 < NC; ++c) {
+                P2(c, std::false_type{});
+                if (j == 1) ICREC_STAMP(4, 5 + 2 * c);
+                bar_lds();
+                if (j == 1) ICREC_STAMP(4, 6 + 2 * c);
+            }
+        }
+    }
 }
 
 // W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.
@@ -1565,6 +1919,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     batch_split(e, T, &T_main, &T_tail);
     const char* fuse_env = getenv("ICREC_FUSE");  // ICREC_FUSE=0: A/B switch to the unfused kernels (read per call: tests flip it)
     const bool fuse = !(fuse_env && fuse_env[0] == '0');
+    const bool persist = !(fuse_env && fuse_env[0] == '2');  // ICREC_FUSE=2: the one-block-per-workgroup fused FFN kernel
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -1598,10 +1953,18 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((Tn + 63) / 64), dim3(256), 0, st, chr, clr, Tn, H,
                                        L.Wo_p, L.bo, xhr, xlr, L.g1, L.b1n, c.ln_eps);
                     ScopedTimer tm(T_FFN_UP, st);
-                    auto kern = ffn_fused2_kernel<0>;
-                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
-                    hipLaunchKernelGGL(kern, dim3((Tn + 63) / 64), dim3(512), FFN2_LDS, st, xhr, xlr, Tn, I, L.W1_p,
-                                       L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
+                    const int nblk = (Tn + 63) / 64;
+                    if (persist) {
+                        auto kern = ffn_fused3_kernel<0>;
+                        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
+                        hipLaunchKernelGGL(kern, dim3(nblk < e->n_cu ? nblk : e->n_cu), dim3(512), FFN2_LDS, st, xhr, xlr, Tn,
+                                           I, L.W1_p, L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
+                    } else {
+                        auto kern = ffn_fused2_kernel<0>;
+                        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
+                        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), FFN2_LDS, st, xhr, xlr, Tn, I, L.W1_p, L.b1, L.W2_p,
+                                           L.b2, L.g2, L.b2n, c.ln_eps);
+                    }
                 } else {
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
                     launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes

@@ -5,7 +5,10 @@
 // Not part of the product; numbers from ablated variants are for attribution only.
 #include "../instacart_next_order_recommendation_amd/csrc/encoder.hip"
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 using namespace icrec;
@@ -44,6 +47,30 @@ static void timeit(const char* name, F&& launch, double flops) {
     hipError_t e = hipGetLastError();
     printf("%-46s min %8.1f us  median %8.1f us  %7.1f TF (algorithmic, median)%s\n", name, ms[0] * 1e3, ms[3] * 1e3,
            flops / (ms[3] * 1e-3) / 1e12, e == hipSuccess ? "" : "  [HIP ERROR]");
+}
+
+// Round-robin comparison: clocks drift with temperature over a run, so variants are timed interleaved (R rounds, one
+// launch of each per round) and compared by their medians.
+struct Cand { const char* name; std::function<void()> launch; std::vector<float> ms; };
+static void compare(std::vector<Cand>& cs, double flops, int rounds = 15) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (auto& c : cs) { c.launch(); c.launch(); }
+    hipDeviceSynchronize();
+    for (int r = 0; r < rounds; ++r)
+        for (auto& c : cs) {
+            hipEventRecord(a);
+            c.launch();
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            float t; hipEventElapsedTime(&t, a, b);
+            c.ms.push_back(t);
+        }
+    for (auto& c : cs) {
+        std::sort(c.ms.begin(), c.ms.end());
+        printf("  [interleaved] %-44s min %8.1f us  median %8.1f us  %7.1f TF\n", c.name, c.ms[0] * 1e3, c.ms[c.ms.size() / 2] * 1e3,
+               flops / (c.ms[c.ms.size() / 2] * 1e-3) / 1e12);
+    }
 }
 
 int main(int argc, char** argv) {
@@ -103,6 +130,37 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
         dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
+        if (T >= 32768) {
+            auto k3 = ffn_fused3_kernel<0>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+            for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k3, dim3(256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+            hipDeviceSynchronize();
+            dump("ffn3 producer wave0 (2nd block)", 256, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26});
+            dump("ffn3 consumer wave4 (2nd block)", 256, 1, {0, 1, 2, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26});
+        }
+        if (T == 131072) {
+            // shader clock under sustained load: s_memtime ticks between the first workgroup's start and the last one's end
+            // of one launch, against that launch's duration by events; `burst` launches back to back before it
+            for (int burst : {0, 40}) {
+                hipEvent_t ea, eb;
+                hipEventCreate(&ea); hipEventCreate(&eb);
+                hipDeviceSynchronize();
+                if (burst == 0) usleep(300000);
+                for (int rep = 0; rep < burst; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+                hipEventRecord(ea);
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+                hipEventRecord(eb);
+                hipEventSynchronize(eb);
+                float ms; hipEventElapsedTime(&ms, ea, eb);
+                std::vector<unsigned long long> hs((size_t)nb * 128);
+                hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_stamps), hs.size() * 8);
+                // the XCDs' counters are not synchronised, so no global first-start / last-end: every workgroup's own life
+                // (start and end stamped on the same CU), summed and divided by the 256 CUs that were busy throughout
+                double busy = 0;
+                for (int b = 0; b < nb; ++b) busy += (double)(hs[(size_t)b * 128 + 30] - hs[(size_t)b * 128 + 0]);
+                printf("fused FFN launch after %2d back-to-back launches: %.1f us by events, %.0f s_memtime ticks of workgroup life per CU -> %.2f GHz\n", burst, ms * 1e3, busy / 256, busy / 256 / (ms * 1e3));
+            }
+        }
         reinit();
         hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         hipDeviceSynchronize();
@@ -140,6 +198,24 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); \
     }, ffn_flops)
         FFN2(0);
+#define FFN3(V)                                                                                                         \
+    timeit("ffn_fused3 (persistent, pipelined blocks) VAR=" #V, [&] {                                                     \
+        auto kern = ffn_fused3_kernel<V>;                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);  \
+        const int nb = (T + 63) / 64;                                                                                    \
+        hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); \
+    }, ffn_flops)
+        FFN3(0);
+        if (T == 131072) {
+            std::vector<Cand> cs;
+            const int nb = (T + 63) / 64;
+#define CAND3(V) { auto kern = ffn_fused3_kernel<V>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS); \
+                   cs.push_back({"ffn_fused3 VAR=" #V, [=] { hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
+            { auto kern = ffn_fused2_kernel<0>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+              cs.push_back({"ffn_fused2", [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
+            CAND3(0) CAND3(2) CAND3(64) CAND3(16) CAND3(32) CAND3(34) CAND3(96) CAND3(8) CAND3(72)
+            compare(cs, ffn_flops);
+        }
         if (T == T0 || T == 131072) {
             FFN2(1); FFN2(4); FFN2(5); FFN2(13); FFN2(16);
         }
