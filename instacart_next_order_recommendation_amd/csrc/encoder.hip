@@ -1691,6 +1691,10 @@ struct Encoder {
     _Float16* planes = nullptr; // packed weight fragments (F16X3)
     float *word, *pos, *type, *eg, *eb;
     LayerW layers[64];
+    // second stream + events: the short remainder of a large batch (batch_split) runs its small-batch kernels beside
+    // the batch kernels of the same layer instead of behind them
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_qkv_tail = nullptr, ev_att = nullptr, ev_tail = nullptr;
 };
 
 static size_t weight_count(const icrec_bert_cfg* c) {
@@ -1845,6 +1849,11 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     }
     ICREC_HIP(hipGetLastError());
     ICREC_HIP(hipDeviceSynchronize());
+    if (x3) {
+        ICREC_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        for (hipEvent_t* ev : {&e->ev_main, &e->ev_qkv_tail, &e->ev_att, &e->ev_tail})
+            ICREC_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
     *out = reinterpret_cast<icrec_encoder*>(e);
     return ICREC_OK;
 }
@@ -1856,6 +1865,12 @@ int icrec_encoder_destroy(icrec_encoder* h) {
     (void)hipFree(e->blob);
     (void)hipFree(e->extra);
     if (e->planes) (void)hipFree(e->planes);
+    if (e->side) {
+        (void)hipStreamSynchronize(e->side);
+        (void)hipStreamDestroy(e->side);
+        for (hipEvent_t ev : {e->ev_main, e->ev_qkv_tail, e->ev_att, e->ev_tail})
+            if (ev) (void)hipEventDestroy(ev);
+    }
     delete e;
     return ICREC_OK;
 }
@@ -1919,7 +1934,9 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     batch_split(e, T, &T_main, &T_tail);
     const char* fuse_env = getenv("ICREC_FUSE");  // ICREC_FUSE=0: A/B switch to the unfused kernels (read per call: tests flip it)
     const bool fuse = !(fuse_env && fuse_env[0] == '0');
-    const bool persist = !(fuse_env && fuse_env[0] == '2');  // ICREC_FUSE=2: the one-block-per-workgroup fused FFN kernel
+    const char* side_env = getenv("ICREC_SIDE_STREAM");  // ICREC_SIDE_STREAM=0: the remainder's kernels stay on the caller's stream (A/B)
+    const bool side_stream = !(side_env && side_env[0] == '0');
+    const bool persist = fuse_env && fuse_env[0] == '3';  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -1940,11 +1957,11 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // Token ranges: [0, T_main) goes through the batch kernels in whole rounds of one 64-token workgroup per
             // CU, a short remainder [T_main, T) through the small-batch kernels (same arithmetic, same bits) instead
             // of costing every batch kernel an extra, almost empty round.
-            auto qkv_stage = [&](int r0, int Tn) {
+            auto qkv_stage = [&](int r0, int Tn, hipStream_t st) {
                 launch_wt_linear<0>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv,
                                     qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
             };
-            auto post_stage = [&](int r0, int Tn) -> int {
+            auto post_stage = [&](int r0, int Tn, hipStream_t st) -> int {
                 float* const t1r = t1 + (size_t)r0 * H;
                 _Float16 *const xhr = xh + (size_t)r0 * H, *const xlr = xl + (size_t)r0 * H;
                 const _Float16 *const chr = ch + (size_t)r0 * H, *const clr = cl + (size_t)r0 * H;
@@ -1980,12 +1997,36 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 }
                 return ICREC_OK;
             };
-            qkv_stage(0, T_main);
-            if (T_tail) qkv_stage(T_main, T_tail);
+            // The remainder's kernels run on the side stream: its QKV beside the batch QKV, its attention-out / FFN chain
+            // beside the batch's.  Attention covers all rows, so it joins both (ev_qkv_tail in, ev_att out); the side
+            // stream's in-order execution keeps its own layers apart.
+            hipStream_t ts = st;
+            if (T_tail && side_stream) {
+                ts = e->side;
+                if (l == 0) {  // the side stream starts behind the embeddings
+                    ICREC_HIP(hipEventRecord(e->ev_main, st));
+                    ICREC_HIP(hipStreamWaitEvent(ts, e->ev_main, 0));
+                }
+                qkv_stage(T_main, T_tail, ts);
+                ICREC_HIP(hipEventRecord(e->ev_qkv_tail, ts));
+            } else if (T_tail) {
+                qkv_stage(T_main, T_tail, st);
+            }
+            qkv_stage(0, T_main, st);
+            if (T_tail && side_stream) ICREC_HIP(hipStreamWaitEvent(st, e->ev_qkv_tail, 0));
             launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
-            if (int rc_ = post_stage(0, T_main)) return rc_;
-            if (T_tail)
-                if (int rc_ = post_stage(T_main, T_tail)) return rc_;
+            if (T_tail) {
+                if (side_stream) {
+                    ICREC_HIP(hipEventRecord(e->ev_att, st));
+                    ICREC_HIP(hipStreamWaitEvent(ts, e->ev_att, 0));
+                }
+                if (int rc_ = post_stage(T_main, T_tail, ts)) return rc_;
+            }
+            if (int rc_ = post_stage(0, T_main, st)) return rc_;
+            if (T_tail && side_stream && l + 1 == c.layers) {  // pooling reads every row: the side stream joins here
+                ICREC_HIP(hipEventRecord(e->ev_tail, ts));
+                ICREC_HIP(hipStreamWaitEvent(st, e->ev_tail, 0));
+            }
         } else {
             launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
             launch_attention<false, false>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);

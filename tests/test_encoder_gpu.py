@@ -173,25 +173,29 @@ def test_two_stream_split_is_bitwise_identical(encoder):
         np.testing.assert_array_equal(one, two)
 
 
-def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch):
+@pytest.mark.parametrize("n_seqs", [19, 400])
+def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, n_seqs):
     """Batches above 512 tokens run attention-out + residual + LN and the whole FFN block (up, GELU, down,
     residual, LN) as two fused kernels; ICREC_FUSE=0 runs the same arithmetic as separate GEMM / LayerNorm
-    launches.  Same per-output MFMA chains and the same ln_row => identical bits."""
+    launches and ICREC_FUSE=3 the persistent, block-pipelined form of the fused FFN kernel (400 sequences:
+    several blocks per workgroup, i.e. its pipelined block boundaries).  Same per-output MFMA chains and the same
+    LayerNorm order => identical bits."""
     import torch
 
     from instacart_next_order_recommendation_amd import synthetic as syn
     from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
 
     enc = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
-    ids, cu = syn.synthetic_token_batch(19, seed=5, mean_len=90, std_len=60, lo=3, hi=256)
-    assert int(cu[-1]) > 512
+    ids, cu = syn.synthetic_token_batch(n_seqs, seed=5, mean_len=90, std_len=60, lo=3, hi=256)
+    assert int(cu[-1]) > (512 if n_seqs == 19 else 2 * 64 * 256)
     mx = int(np.diff(cu).max())
     args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), mx)
     fused = enc.encode_packed(*args).cpu().numpy()
-    monkeypatch.setenv("ICREC_FUSE", "0")
-    unfused = enc.encode_packed(*args).cpu().numpy()
-    monkeypatch.delenv("ICREC_FUSE")
-    np.testing.assert_array_equal(fused, unfused)
+    for mode in ("0", "3"):
+        monkeypatch.setenv("ICREC_FUSE", mode)
+        other = enc.encode_packed(*args).cpu().numpy()
+        monkeypatch.delenv("ICREC_FUSE")
+        np.testing.assert_array_equal(fused, other)
     enc.close()
 
 
