@@ -1694,7 +1694,7 @@ struct Encoder {
     // second stream + events: the short remainder of a large batch (batch_split) runs its small-batch kernels beside
     // the batch kernels of the same layer instead of behind them
     hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_qkv_tail = nullptr, ev_att = nullptr, ev_tail = nullptr;
+    hipEvent_t ev_main = nullptr, ev_qkv_tail = nullptr, ev_att = nullptr, ev_tail = nullptr, ev_q = nullptr, ev_sa = nullptr;
 };
 
 static size_t weight_count(const icrec_bert_cfg* c) {
@@ -1754,7 +1754,8 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
 // costs a few microseconds; single-sequence calls launch exactly one bucket).
 template <bool SPLIT, bool X3>
 static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
-                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st) {
+                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st, int buckets = 15) {
+    // buckets: bit b set = launch the bucket of 2^b key tiles (callers split the buckets over two streams)
     const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
     const int nkt_max = (max_seqlen + 31) / 32;
     const bool single = n_seqs == 1;
@@ -1764,10 +1765,10 @@ static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, in
         if (X3) hipLaunchKernelGGL((attention_x3_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl); \
         else hipLaunchKernelGGL((attention_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);      \
     } while (0)
-    if (single ? nkt_max == 1 : true) ICREC_ATT(1, 1);
-    if (single ? nkt_max == 2 : nkt_max >= 2) ICREC_ATT(2, 2);
-    if (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3) ICREC_ATT(4, 4);
-    if (nkt_max >= 5) ICREC_ATT(8, 8);
+    if ((buckets & 1) && (single ? nkt_max == 1 : true)) ICREC_ATT(1, 1);
+    if ((buckets & 2) && (single ? nkt_max == 2 : nkt_max >= 2)) ICREC_ATT(2, 2);
+    if ((buckets & 4) && (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)) ICREC_ATT(4, 4);
+    if ((buckets & 8) && nkt_max >= 5) ICREC_ATT(8, 8);
 #undef ICREC_ATT
 }
 
@@ -1851,7 +1852,7 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     ICREC_HIP(hipDeviceSynchronize());
     if (x3) {
         ICREC_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        for (hipEvent_t* ev : {&e->ev_main, &e->ev_qkv_tail, &e->ev_att, &e->ev_tail})
+        for (hipEvent_t* ev : {&e->ev_main, &e->ev_qkv_tail, &e->ev_att, &e->ev_tail, &e->ev_q, &e->ev_sa})
             ICREC_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     *out = reinterpret_cast<icrec_encoder*>(e);
@@ -1868,7 +1869,7 @@ int icrec_encoder_destroy(icrec_encoder* h) {
     if (e->side) {
         (void)hipStreamSynchronize(e->side);
         (void)hipStreamDestroy(e->side);
-        for (hipEvent_t ev : {e->ev_main, e->ev_qkv_tail, e->ev_att, e->ev_tail})
+        for (hipEvent_t ev : {e->ev_main, e->ev_qkv_tail, e->ev_att, e->ev_tail, e->ev_q, e->ev_sa})
             if (ev) (void)hipEventDestroy(ev);
     }
     delete e;
@@ -1936,7 +1937,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const bool fuse = !(fuse_env && fuse_env[0] == '0');
     const char* side_env = getenv("ICREC_SIDE_STREAM");  // ICREC_SIDE_STREAM=0: the remainder's kernels stay on the caller's stream (A/B)
     const bool side_stream = !(side_env && side_env[0] == '0');
-    const bool persist = fuse_env && fuse_env[0] == '3';  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
+    const bool persist = fuse_env && fuse_env[0] == '3';
+    const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -2014,7 +2016,18 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             }
             qkv_stage(0, T_main, st);
             if (T_tail && side_stream) ICREC_HIP(hipStreamWaitEvent(st, e->ev_qkv_tail, 0));
-            launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            if (split_att) {
+                // the long bucket keeps one 8-wave workgroup per CU busy (LDS) with issue slots to spare: the shorter
+                // buckets' workgroups run beside it from the side stream instead of after it
+                ICREC_HIP(hipEventRecord(e->ev_q, st));
+                ICREC_HIP(hipStreamWaitEvent(e->side, e->ev_q, 0));
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, e->side, 7);
+                ICREC_HIP(hipEventRecord(e->ev_sa, e->side));
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 8);
+                ICREC_HIP(hipStreamWaitEvent(st, e->ev_sa, 0));
+            } else {
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+            }
             if (T_tail) {
                 if (side_stream) {
                     ICREC_HIP(hipEventRecord(e->ev_att, st));
