@@ -9,7 +9,9 @@
 // and oracle/icrec_oracle.c reduction orders where a kernel says "oracle order".
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "gemm_x3.h"
@@ -1516,39 +1518,50 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
             }
         }
     }
+    // Softmax on the raw scores (S' = 256 S): the keys beyond the sequence are masked in the one tile that has any
+    // (uniform branch), the maximum is taken before scaling, and scale, shift and the 2^10 factor of p' = 1024 p go
+    // into one fma in front of the exponential: p' = 2^(S' cs - max' cs + 10).
     const float cs = scale_log2e * (1.0f / 256.0f);  // scores in log2 units from S' = 256 S
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+        if (kt == nkt - 1 && kt * 32 + 32 > L) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (kt * 32 + acc_row(e, lane) >= L) sc[kt][e] = -INFINITY;
+        }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         if (kt < nkt) {
-            const bool last = kt == nkt - 1;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = sc[kt][e] * cs;
-                if (last && kt * 32 + acc_row(e, lane) >= L) v = -INFINITY;
-                sc[kt][e] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[kt][e]);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) - 10.0f;  // p' = 2^(v - max + 10) = 1024 p
-    float lsum = 0.0f;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float shift = fmaf(-mx, cs, 10.0f);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         if (kt < nkt) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
-                sc[kt][e] = p;
-                lsum = lsum + p;
-            }
+            for (int e = 0; e < 16; ++e) sc[kt][e] = __builtin_amdgcn_exp2f(fmaf(sc[kt][e], cs, shift));
         }
     }
-    {
-        const float other = __shfl_xor(lsum, 32, 64);
-        lsum = h == 0 ? lsum + other : other + lsum;
+    // row sums l' = sum_k p'_k: two interleaved chains per lane (packed adds), the halves of a row joined by a shuffle
+    typedef float float2w __attribute__((ext_vector_type(2)));
+    float2w ls2 = float2w{0.0f, 0.0f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) ls2 = ls2 + float2w{sc[kt][e], sc[kt][e + 1]};
+        }
     }
-    if (h == 0) Ls[wave * 32 + r] = lsum;
+    float lrow = ls2[0] + ls2[1];
+    {
+        const float other = __shfl_xor(lrow, 32, 64);
+        lrow = h == 0 ? lrow + other : other + lrow;
+    }
+    if (h == 0) Ls[wave * 32 + r] = lrow;
     ICREC_STAMP(0, 3);
 
     f32x16 o;
@@ -1691,11 +1704,31 @@ struct Encoder {
     _Float16* planes = nullptr; // packed weight fragments (F16X3)
     float *word, *pos, *type, *eg, *eb;
     LayerW layers[64];
-    // second stream + events: the short remainder of a large batch (batch_split) runs its small-batch kernels beside
-    // the batch kernels of the same layer instead of behind them
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_qkv_tail = nullptr, ev_att = nullptr, ev_tail = nullptr, ev_q = nullptr, ev_sa = nullptr;
+    // Side stream + events of one caller stream: the short remainder of a large batch (batch_split) and the shorter
+    // attention buckets run beside the batch kernels of the same layer instead of behind them.  One set per caller
+    // stream (created on first use, kept for the encoder's life), so that concurrent icrec_encode calls on different
+    // streams - DeviceEncoder runs the two halves of a batch that way - do not queue behind each other's side work.
+    struct Side {
+        hipStream_t caller = nullptr, side = nullptr;
+        hipEvent_t ev_main = nullptr, ev_qkv_tail = nullptr, ev_att = nullptr, ev_tail = nullptr, ev_q = nullptr, ev_sa = nullptr;
+    };
+    std::mutex side_mu;
+    std::vector<Side*> sides;
 };
+
+static int side_for(Encoder* e, hipStream_t caller, Encoder::Side** out) {
+    std::lock_guard<std::mutex> lock(e->side_mu);
+    for (Encoder::Side* sd : e->sides)
+        if (sd->caller == caller) { *out = sd; return ICREC_OK; }
+    Encoder::Side* sd = new Encoder::Side();
+    sd->caller = caller;
+    ICREC_HIP(hipStreamCreateWithFlags(&sd->side, hipStreamNonBlocking));
+    for (hipEvent_t* ev : {&sd->ev_main, &sd->ev_qkv_tail, &sd->ev_att, &sd->ev_tail, &sd->ev_q, &sd->ev_sa})
+        ICREC_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    e->sides.push_back(sd);
+    *out = sd;
+    return ICREC_OK;
+}
 
 static size_t weight_count(const icrec_bert_cfg* c) {
     const size_t H = c->hidden, I = c->intermediate;
@@ -1850,11 +1883,6 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     }
     ICREC_HIP(hipGetLastError());
     ICREC_HIP(hipDeviceSynchronize());
-    if (x3) {
-        ICREC_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-        for (hipEvent_t* ev : {&e->ev_main, &e->ev_qkv_tail, &e->ev_att, &e->ev_tail, &e->ev_q, &e->ev_sa})
-            ICREC_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    }
     *out = reinterpret_cast<icrec_encoder*>(e);
     return ICREC_OK;
 }
@@ -1866,11 +1894,14 @@ int icrec_encoder_destroy(icrec_encoder* h) {
     (void)hipFree(e->blob);
     (void)hipFree(e->extra);
     if (e->planes) (void)hipFree(e->planes);
-    if (e->side) {
-        (void)hipStreamSynchronize(e->side);
-        (void)hipStreamDestroy(e->side);
-        for (hipEvent_t ev : {e->ev_main, e->ev_qkv_tail, e->ev_att, e->ev_tail, e->ev_q, e->ev_sa})
+    for (Encoder::Side* sd : e->sides) {
+        if (sd->side) {
+            (void)hipStreamSynchronize(sd->side);
+            (void)hipStreamDestroy(sd->side);
+        }
+        for (hipEvent_t ev : {sd->ev_main, sd->ev_qkv_tail, sd->ev_att, sd->ev_tail, sd->ev_q, sd->ev_sa})
             if (ev) (void)hipEventDestroy(ev);
+        delete sd;
     }
     delete e;
     return ICREC_OK;
@@ -1938,7 +1969,10 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const char* side_env = getenv("ICREC_SIDE_STREAM");  // ICREC_SIDE_STREAM=0: the remainder's kernels stay on the caller's stream (A/B)
     const bool side_stream = !(side_env && side_env[0] == '0');
     const bool persist = fuse_env && fuse_env[0] == '3';
-    const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
+    const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
+    Encoder::Side* sd = nullptr;
+    if (x3 && side_stream && (T_tail || split_att))
+        if (int rc_ = side_for(e, st, &sd)) return rc_;  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -2004,41 +2038,41 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // stream's in-order execution keeps its own layers apart.
             hipStream_t ts = st;
             if (T_tail && side_stream) {
-                ts = e->side;
+                ts = sd->side;
                 if (l == 0) {  // the side stream starts behind the embeddings
-                    ICREC_HIP(hipEventRecord(e->ev_main, st));
-                    ICREC_HIP(hipStreamWaitEvent(ts, e->ev_main, 0));
+                    ICREC_HIP(hipEventRecord(sd->ev_main, st));
+                    ICREC_HIP(hipStreamWaitEvent(ts, sd->ev_main, 0));
                 }
                 qkv_stage(T_main, T_tail, ts);
-                ICREC_HIP(hipEventRecord(e->ev_qkv_tail, ts));
+                ICREC_HIP(hipEventRecord(sd->ev_qkv_tail, ts));
             } else if (T_tail) {
                 qkv_stage(T_main, T_tail, st);
             }
             qkv_stage(0, T_main, st);
-            if (T_tail && side_stream) ICREC_HIP(hipStreamWaitEvent(st, e->ev_qkv_tail, 0));
+            if (T_tail && side_stream) ICREC_HIP(hipStreamWaitEvent(st, sd->ev_qkv_tail, 0));
             if (split_att) {
                 // the long bucket keeps one 8-wave workgroup per CU busy (LDS) with issue slots to spare: the shorter
                 // buckets' workgroups run beside it from the side stream instead of after it
-                ICREC_HIP(hipEventRecord(e->ev_q, st));
-                ICREC_HIP(hipStreamWaitEvent(e->side, e->ev_q, 0));
-                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, e->side, 7);
-                ICREC_HIP(hipEventRecord(e->ev_sa, e->side));
+                ICREC_HIP(hipEventRecord(sd->ev_q, st));
+                ICREC_HIP(hipStreamWaitEvent(sd->side, sd->ev_q, 0));
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, sd->side, 7);
+                ICREC_HIP(hipEventRecord(sd->ev_sa, sd->side));
                 launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 8);
-                ICREC_HIP(hipStreamWaitEvent(st, e->ev_sa, 0));
+                ICREC_HIP(hipStreamWaitEvent(st, sd->ev_sa, 0));
             } else {
                 launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
             }
             if (T_tail) {
                 if (side_stream) {
-                    ICREC_HIP(hipEventRecord(e->ev_att, st));
-                    ICREC_HIP(hipStreamWaitEvent(ts, e->ev_att, 0));
+                    ICREC_HIP(hipEventRecord(sd->ev_att, st));
+                    ICREC_HIP(hipStreamWaitEvent(ts, sd->ev_att, 0));
                 }
                 if (int rc_ = post_stage(T_main, T_tail, ts)) return rc_;
             }
             if (int rc_ = post_stage(0, T_main, st)) return rc_;
             if (T_tail && side_stream && l + 1 == c.layers) {  // pooling reads every row: the side stream joins here
-                ICREC_HIP(hipEventRecord(e->ev_tail, ts));
-                ICREC_HIP(hipStreamWaitEvent(st, e->ev_tail, 0));
+                ICREC_HIP(hipEventRecord(sd->ev_tail, ts));
+                ICREC_HIP(hipStreamWaitEvent(st, sd->ev_tail, 0));
             }
         } else {
             launch_linear<false>(x, T, H, L.Wqkv, 3 * H, L.bqkv, qkv, st);
