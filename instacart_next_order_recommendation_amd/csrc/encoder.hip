@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
 }
 
 template <int NKT, int WAVES, bool SPLIT>
-__global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_kernel(const float* __restrict__ qkv,
                                                                   const int32_t* __restrict__ cu, int heads, int H,
                                                                   float scale_log2e, float* __restrict__ ctx,
                                                                   _Float16* __restrict__ ch, _Float16* __restrict__ cl) {
@@ -1429,13 +1429,23 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
     // or 1024 p (the probabilities), the three products of a k-step accumulate into ONE fp32 tile, and the power-of-two
     // scales are folded into constants: S' = 256 S, O' = 16384 sum_k p_k V_k, l' = 1024 sum_k p_k, O = O' / (16 l').
     // All splits are the 3-instruction form (mask / subtract / v_cvt_pkrtz pairs).
+    //
+    // Long bucket (NKT = 8, RECOMP): the score tiles are computed TWICE - once for the row maximum, once more for the
+    // exponentials, each tile consumed by the PV product as soon as it exists - instead of all eight being held in
+    // 128 registers between the two passes.  Same MFMA chains, same order of every sum: the same bits, 48 more MFMAs
+    // per wave on an idle matrix pipe, and the kernel drops under 128 VGPRs; with the output tile parked on the K
+    // planes (behind one more barrier) it also drops to 67 KB of LDS - TWO workgroups per CU, so one's staging and
+    // barrier phases run under the other's arithmetic.
+    constexpr bool RECOMP = NKT >= 8;
     constexpr int VT = NKT * 32 + 4;  // V^T row stride in halfs (+8 B: the 32 dims land on distinct banks)
-    __shared__ __attribute__((aligned(16))) _Float16 Kh[NKT * 32 * 32];
-    __shared__ __attribute__((aligned(16))) _Float16 Kl[NKT * 32 * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Kbuf[2 * NKT * 32 * 32];
+    _Float16* const Kh = Kbuf;
+    _Float16* const Kl = Kbuf + NKT * 32 * 32;
     __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VT];
     __shared__ __attribute__((aligned(16))) _Float16 Vl[32 * VT];
     __shared__ float Ls[WAVES * 32];
-    __shared__ __attribute__((aligned(16))) _Float16 Ob[(SPLIT && NKT >= 8) ? WAVES * 2 * 32 * 32 : 8];  // per-wave output tile (hi | lo), long bucket only
+    static_assert(!RECOMP || WAVES * 2 * 32 * 32 <= 2 * NKT * 32 * 32, "the output tiles reuse the K planes");
+    _Float16* const Ob = Kbuf;  // per-wave output tile (hi | lo), long bucket only: aliases K after the second barrier
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
@@ -1498,37 +1508,103 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
     ICREC_STAMP(0, 1);
     __syncthreads();
     ICREC_STAMP(0, 2);
-    if (qb >= nkt) return;  // idle wave (no barrier below)
+    const bool active = qb < nkt;
+    if (!RECOMP && !active) return;  // idle wave (no barrier below)
 
-    f32x16 sc[NKT];
+    // raw scores S' = 256 S of key tile kt for this wave's 32 queries, keys beyond the sequence at -inf (only the one
+    // tile that has any pays for the selects: uniform branch)
+    auto score_tile = [&](int kt) {
+        f32x16 t;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+        for (int e = 0; e < 16; ++e) t[e] = 0.0f;
+        const int key = kt * 32 + r;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.0f;
-        if (kt < nkt) {
-            const int key = kt * 32 + r;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = key * 32 + (((2 * ks + h) ^ ((key >> 2) & 3)) << 3);
-                const half8 kh = *reinterpret_cast<const half8*>(Kh + off);
-                const half8 kl = *reinterpret_cast<const half8*>(Kl + off);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sc[kt], 0, 0, 0);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc[kt], 0, 0, 0);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc[kt], 0, 0, 0);
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = key * 32 + (((2 * ks + h) ^ ((key >> 2) & 3)) << 3);
+            const half8 kh = *reinterpret_cast<const half8*>(Kh + off);
+            const half8 kl = *reinterpret_cast<const half8*>(Kl + off);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], t, 0, 0, 0);
         }
-    }
-    // Softmax on the raw scores (S' = 256 S): the keys beyond the sequence are masked in the one tile that has any
-    // (uniform branch), the maximum is taken before scaling, and scale, shift and the 2^10 factor of p' = 1024 p go
-    // into one fma in front of the exponential: p' = 2^(S' cs - max' cs + 10).
-    const float cs = scale_log2e * (1.0f / 256.0f);  // scores in log2 units from S' = 256 S
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
         if (kt == nkt - 1 && kt * 32 + 32 > L) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (kt * 32 + acc_row(e, lane) >= L) sc[kt][e] = -INFINITY;
+                if (kt * 32 + acc_row(e, lane) >= L) t[e] = -INFINITY;
         }
+        return t;
+    };
+    // P (a tile of p' = 1024 p in the accumulator layout) times V, into o
+    auto pv_tile = [&](int kt, const f32x16& pt, f32x16& o) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                half2w a, b;
+                split_pair_prescaled(pt[8 * ks + j], pt[8 * ks + j + 1], a, b);
+                ph[j] = a[0]; ph[j + 1] = a[1];
+                pl[j] = b[0]; pl[j + 1] = b[1];
+            }
+            // this lane's head dim r, keys base .. base+3 and base+8 .. base+11
+            const int base = kt * 32 + 4 * h + 16 * ks;
+            const half4 v0h = *reinterpret_cast<const half4*>(Vh + r * VT + base);
+            const half4 v1h = *reinterpret_cast<const half4*>(Vh + r * VT + base + 8);
+            const half4 v0l = *reinterpret_cast<const half4*>(Vl + r * VT + base);
+            const half4 v1l = *reinterpret_cast<const half4*>(Vl + r * VT + base + 8);
+            const half8 vh = {v0h[0], v0h[1], v0h[2], v0h[3], v1h[0], v1h[1], v1h[2], v1h[3]};
+            const half8 vl = {v0l[0], v0l[1], v0l[2], v0l[3], v1l[0], v1l[1], v1l[2], v1l[3]};
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o, 0, 0, 0);
+        }
+    };
+    typedef float float2w __attribute__((ext_vector_type(2)));
+    const float cs = scale_log2e * (1.0f / 256.0f);  // scores in log2 units from S' = 256 S
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+    if (RECOMP) {
+        if (active) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt < nkt) {
+                    const f32x16 t = score_tile(kt);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float shift = fmaf(-mx, cs, 10.0f);
+            float2w ls2 = float2w{0.0f, 0.0f};
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt < nkt) {
+                    f32x16 t = score_tile(kt);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) t[e] = __builtin_amdgcn_exp2f(fmaf(t[e], cs, shift));
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) ls2 = ls2 + float2w{t[e], t[e + 1]};
+                    pv_tile(kt, t, o);
+                }
+            }
+            float lrow = ls2[0] + ls2[1];
+            const float other = __shfl_xor(lrow, 32, 64);
+            lrow = h == 0 ? lrow + other : other + lrow;
+            if (h == 0) Ls[wave * 32 + r] = lrow;
+        }
+        ICREC_STAMP(0, 3);
+        __syncthreads();  // every wave has left the K planes: they become the output tiles
+        if (!active) return;
+    } else {
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) sc[kt] = score_tile(kt);
+    // Softmax on the raw scores (S' = 256 S): the keys beyond the sequence are masked in the one tile that has any
+    // (uniform branch), the maximum is taken before scaling, and scale, shift and the 2^10 factor of p' = 1024 p go
+    // into one fma in front of the exponential: p' = 2^(S' cs - max' cs + 10).
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -1547,7 +1623,6 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
         }
     }
     // row sums l' = sum_k p'_k: two interleaved chains per lane (packed adds), the halves of a row joined by a shuffle
-    typedef float float2w __attribute__((ext_vector_type(2)));
     float2w ls2 = float2w{0.0f, 0.0f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -1564,35 +1639,9 @@ __global__ __launch_bounds__(WAVES * 64) void attention_x3_kernel(const float* _
     if (h == 0) Ls[wave * 32 + r] = lrow;
     ICREC_STAMP(0, 3);
 
-    f32x16 o;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                half8 ph, pl;
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    half2w a, b;
-                    split_pair_prescaled(sc[kt][8 * ks + j], sc[kt][8 * ks + j + 1], a, b);
-                    ph[j] = a[0]; ph[j + 1] = a[1];
-                    pl[j] = b[0]; pl[j + 1] = b[1];
-                }
-                // this lane's head dim r, keys base .. base+3 and base+8 .. base+11
-                const int base = kt * 32 + 4 * h + 16 * ks;
-                const half4 v0h = *reinterpret_cast<const half4*>(Vh + r * VT + base);
-                const half4 v1h = *reinterpret_cast<const half4*>(Vh + r * VT + base + 8);
-                const half4 v0l = *reinterpret_cast<const half4*>(Vl + r * VT + base);
-                const half4 v1l = *reinterpret_cast<const half4*>(Vl + r * VT + base + 8);
-                const half8 vh = {v0h[0], v0h[1], v0h[2], v0h[3], v1h[0], v1h[1], v1h[2], v1h[3]};
-                const half8 vl = {v0l[0], v0l[1], v0l[2], v0l[3], v1l[0], v1l[1], v1l[2], v1l[3]};
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, o, 0, 0, 0);
-            }
-        }
+    for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) pv_tile(kt, sc[kt], o);
     }
     ICREC_STAMP(0, 4);
     if (SPLIT && NKT >= 8) {
