@@ -137,9 +137,13 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
                          "algorithmic FLOPs; against the raw f16 dense peak the fraction is frac_of_f16_dense_peak",
             "frac_of_f16_dense_peak": achieved / PEAK_F16_MFMA_TFLOPS,
             "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
-            "algorithmic_bytes": tokens * 384 * (4 + 4 + 4 + 4) + 2 * 2 * 1536 * 384 * 2,
-            "algorithmic_bytes_note": "x planes in (4 B/elt) + fp32 residual in + fp32 x out + planes out, + the layer's "
-                                      "packed W1/W2 fragments once",
+            "algorithmic_bytes": tokens * 384 * (4 + 4) + 2 * 2 * 1536 * 384 * 2,
+            "algorithmic_bytes_note": "x planes in (2 x 2 B/elt: GEMM operand and residual at once) + x planes out, + the "
+                                      "layer's packed W1/W2 fragments once",
+            "clock_note": "under this kernel the shader clock sustains 1.6-1.75 GHz of the 2.4 GHz the peak assumes "
+                          "(s_memtime vs hipEvents in tools/ffn_bench.hip, GRBM_GUI_ACTIVE in profiles/r02_pmc_per_kernel.txt): "
+                          "frac_at_measured_clock prices the same launch against the roof at 1.7 GHz",
+            "frac_at_measured_clock": achieved / (peak * 1.7 / 2.4),
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
 
