@@ -110,7 +110,13 @@ ICREC_API size_t icrec_encode_workspace_bytes(const icrec_encoder* enc,
  *   max_seqlen     longest sequence in the batch (<= 256 in this build)
  *   out_dev        float[n_seqs, hidden] L2-normalised sentence embeddings
  * Padding never enters the math: the reference pads per batch and masks the
- * pad keys to weight exactly 0, so the packed form is the same function.     */
+ * pad keys to weight exactly 0, so the packed form is the same function.
+ * Stream semantics: asynchronous on `stream`; everything the call enqueues is ordered before whatever the caller
+ * enqueues on `stream` afterwards.  For large batches (f16x3 mode) part of the work - the short attention buckets, the
+ * remainder of icrec_encode_batch_split - runs on a library-owned side stream (one per caller stream, created on
+ * first use) that forks from and joins back into `stream` by events inside the call; under stream capture the call
+ * stays on `stream` unless that side stream already exists.  Calls on DIFFERENT streams may run concurrently (own
+ * workspaces); calls on one encoder must not be issued from several host threads at once. */
 ICREC_API int icrec_encode(icrec_encoder* enc,
                  const int32_t* ids_dev, const int32_t* cu_seqlens_dev,
                  int32_t n_seqs, int64_t total_tokens, int32_t max_seqlen,

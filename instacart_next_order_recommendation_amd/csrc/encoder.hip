@@ -1767,8 +1767,12 @@ struct Encoder {
 
 static int side_for(Encoder* e, hipStream_t caller, Encoder::Side** out) {
     std::lock_guard<std::mutex> lock(e->side_mu);
+    *out = nullptr;
     for (Encoder::Side* sd : e->sides)
         if (sd->caller == caller) { *out = sd; return ICREC_OK; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (caller && hipStreamIsCapturing(caller, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return ICREC_OK;  // no stream / event creation inside a capture: the call stays on the caller's stream
     Encoder::Side* sd = new Encoder::Side();
     sd->caller = caller;
     ICREC_HIP(hipStreamCreateWithFlags(&sd->side, hipStreamNonBlocking));
@@ -2021,7 +2025,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
     Encoder::Side* sd = nullptr;
     if (x3 && side_stream && (T_tail || split_att))
-        if (int rc_ = side_for(e, st, &sd)) return rc_;  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
+        if (int rc_ = side_for(e, st, &sd)) return rc_;
+    const bool use_side = sd != nullptr;  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -2086,7 +2091,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // beside the batch's.  Attention covers all rows, so it joins both (ev_qkv_tail in, ev_att out); the side
             // stream's in-order execution keeps its own layers apart.
             hipStream_t ts = st;
-            if (T_tail && side_stream) {
+            if (T_tail && use_side) {
                 ts = sd->side;
                 if (l == 0) {  // the side stream starts behind the embeddings
                     ICREC_HIP(hipEventRecord(sd->ev_main, st));
@@ -2098,8 +2103,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 qkv_stage(T_main, T_tail, st);
             }
             qkv_stage(0, T_main, st);
-            if (T_tail && side_stream) ICREC_HIP(hipStreamWaitEvent(st, sd->ev_qkv_tail, 0));
-            if (split_att) {
+            if (T_tail && use_side) ICREC_HIP(hipStreamWaitEvent(st, sd->ev_qkv_tail, 0));
+            if (split_att && use_side) {
                 // the long bucket keeps one 8-wave workgroup per CU busy (LDS) with issue slots to spare: the shorter
                 // buckets' workgroups run beside it from the side stream instead of after it
                 ICREC_HIP(hipEventRecord(sd->ev_q, st));
@@ -2112,14 +2117,14 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
             }
             if (T_tail) {
-                if (side_stream) {
+                if (use_side) {
                     ICREC_HIP(hipEventRecord(sd->ev_att, st));
                     ICREC_HIP(hipStreamWaitEvent(ts, sd->ev_att, 0));
                 }
                 if (int rc_ = post_stage(T_main, T_tail, ts)) return rc_;
             }
             if (int rc_ = post_stage(0, T_main, st)) return rc_;
-            if (T_tail && side_stream && l + 1 == c.layers) {  // pooling reads every row: the side stream joins here
+            if (T_tail && use_side && l + 1 == c.layers) {  // pooling reads every row: the side stream joins here
                 ICREC_HIP(hipEventRecord(sd->ev_tail, ts));
                 ICREC_HIP(hipStreamWaitEvent(st, sd->ev_tail, 0));
             }
