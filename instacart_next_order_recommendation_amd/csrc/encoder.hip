@@ -901,8 +901,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
 // the producers' iteration 1.  The next block's activation planes travel global -> registers -> LDS inside the
 // drain epoch (the producers' MFMA-free epoch: weight ring, S and the fragment registers are idle), into the X
 // region that P1(11) has just left.  Arithmetic and order per output are those of ffn_fused2_kernel.
-// VAR: timing experiments of tools/ffn_bench.hip (the product uses 0).
-template <int VAR>
 __global__ __launch_bounds__(512, 2) void ffn_fused3_kernel(_Float16* __restrict__ xh, _Float16* __restrict__ xl,
                                                             int T, int I, const _Float16* __restrict__ W1p,
                                                             const float* __restrict__ b1,
@@ -1087,8 +1085,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused3_kernel(_Float16* __restrict
                 for (int g = 0; g < 4; ++g) biasp[g] = bias[g];
             }
         };
-        if (VAR & 2) __builtin_amdgcn_s_setprio(2);
-        if (VAR & 64) __builtin_amdgcn_s_setprio(3);
         for (int j = 0; j < J; ++j) {
             {   // an opaque zero OFFSET (not an opaque pointer: that would turn the loads into flat_load, which count
                 // against lgkmcnt as well and serialise with the LDS fragment reads)
@@ -1154,13 +1150,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused3_kernel(_Float16* __restrict
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 wt_mma<3, 2>(Y, wh[k2 & 3], wl[k2 & 3], fh[k2 & 1], fl[k2 & 1]);
-                if (VAR & 1) __builtin_amdgcn_s_sleep(4);
-                if (VAR & 4) __builtin_amdgcn_s_sleep(2);
                 if (!LAST || k2 < 4) w_load<3>(wh[k2 & 3], wl[k2 & 3], w2p, c * 8 + k2 + 4, lo8);
-                if (VAR & 8) __builtin_amdgcn_s_sleep(4);
-                if (VAR & 16) __builtin_amdgcn_s_sleep(2);
-                if (VAR & 32) __builtin_amdgcn_s_sleep(3);
-                if (VAR & 128) __builtin_amdgcn_s_sleep(6);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -2062,7 +2052,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     ScopedTimer tm(T_FFN_UP, st);
                     const int nblk = (Tn + 63) / 64;
                     if (persist) {
-                        auto kern = ffn_fused3_kernel<0>;
+                        auto kern = ffn_fused3_kernel;
                         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
                         hipLaunchKernelGGL(kern, dim3(nblk < e->n_cu ? nblk : e->n_cu), dim3(512), FFN2_LDS, st, xhr, xlr, Tn,
                                            I, L.W1_p, L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);

@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
         dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
         dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
         if (T >= 32768) {
-            auto k3 = ffn_fused3_kernel<0>;
+            auto k3 = ffn_fused3_kernel;
             hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
             for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k3, dim3(256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
             hipDeviceSynchronize();
@@ -158,7 +158,7 @@ int main(int argc, char** argv) {
                 // (start and end stamped on the same CU), summed and divided by the 256 CUs that were busy throughout
                 double busy = 0;
                 for (int b = 0; b < nb; ++b) busy += (double)(hs[(size_t)b * 128 + 30] - hs[(size_t)b * 128 + 0]);
-                printf("fused FFN launch after %2d back-to-back launches: %.1f us by events, %.0f s_memtime ticks of workgroup life per CU -> %.2f GHz\n", burst, ms * 1e3, busy / 256, busy / 256 / (ms * 1e3));
+                printf("fused FFN launch after %2d back-to-back launches: %.1f us by events, %.0f s_memtime ticks of workgroup life per CU -> %.2f GHz\n", burst, ms * 1e3, busy / 256, busy / 256 / (ms * 1e6));
             }
         }
         reinit();
@@ -198,22 +198,19 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); \
     }, ffn_flops)
         FFN2(0);
-#define FFN3(V)                                                                                                         \
-    timeit("ffn_fused3 (persistent, pipelined blocks) VAR=" #V, [&] {                                                     \
-        auto kern = ffn_fused3_kernel<V>;                                                                                \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);  \
-        const int nb = (T + 63) / 64;                                                                                    \
-        hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); \
-    }, ffn_flops)
-        FFN3(0);
-        if (T == 131072) {
+        timeit("ffn_fused3 (persistent, pipelined blocks)", [&] {
+            auto kern = ffn_fused3_kernel;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+            const int nb = (T + 63) / 64;
+            hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+        }, ffn_flops);
+        if (T == 131072) {  // the two fused kernels timed interleaved (clocks drift over a run)
             std::vector<Cand> cs;
             const int nb = (T + 63) / 64;
-#define CAND3(V) { auto kern = ffn_fused3_kernel<V>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS); \
-                   cs.push_back({"ffn_fused3 VAR=" #V, [=] { hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
             { auto kern = ffn_fused2_kernel<0>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
               cs.push_back({"ffn_fused2", [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
-            CAND3(0) CAND3(2) CAND3(64) CAND3(16) CAND3(32) CAND3(34) CAND3(96) CAND3(8) CAND3(72)
+            { auto kern = ffn_fused3_kernel; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+              cs.push_back({"ffn_fused3", [=] { hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
             compare(cs, ffn_flops);
         }
         if (T == T0 || T == 131072) {
