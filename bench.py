@@ -140,10 +140,10 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
             "algorithmic_bytes": tokens * 384 * (4 + 4) + 2 * 2 * 1536 * 384 * 2,
             "algorithmic_bytes_note": "x planes in (2 x 2 B/elt: GEMM operand and residual at once) + x planes out, + the "
                                       "layer's packed W1/W2 fragments once",
-            "clock_note": "under this kernel the shader clock sustains 1.6-1.75 GHz of the 2.4 GHz the peak assumes "
-                          "(s_memtime vs hipEvents in tools/ffn_bench.hip, GRBM_GUI_ACTIVE in profiles/r02_pmc_per_kernel.txt): "
-                          "frac_at_measured_clock prices the same launch against the roof at 1.7 GHz",
-            "frac_at_measured_clock": achieved / (peak * 1.7 / 2.4),
+            "ceiling_note": "a registers-only loop of the same MFMA instruction sustains 2,012 TFLOP/s f16 dense on this chip "
+                            "(tools/mfma_peak.hip, profiles/r02_mfma_sustained_rate.txt: the clock falls under matrix load), i.e. "
+                            "671 TFLOP/s of f16x3 products: frac_of_measured_mfma_ceiling prices the launch against that",
+            "frac_of_measured_mfma_ceiling": achieved / (2012.0 / 3.0),
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
 
