@@ -199,6 +199,49 @@ def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, 
     enc.close()
 
 
+def test_side_stream_changes_nothing(minilm_weights, monkeypatch):
+    """A batch of whole 64-token-per-CU rounds + a short remainder: the remainder's small-batch kernels and the short
+    attention buckets run on the library's side stream (fork / join by events inside icrec_encode).
+    ICREC_SIDE_STREAM=0 keeps every kernel on the caller's stream: same bits, and repeated calls stay identical."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import _native, synthetic as syn
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+
+    enc = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    ids, cu = syn.synthetic_token_batch(400, seed=11, mean_len=90, std_len=60, lo=3, hi=256)
+    import ctypes as C
+
+    def split(tokens):
+        m, t = C.c_int64(0), C.c_int64(0)
+        _native.check(_native.lib().icrec_encode_batch_split(enc._h, tokens, C.byref(m), C.byref(t)), "icrec_encode_batch_split")
+        return int(m.value), int(t.value)
+
+    main_t, tail_t, n = 0, 0, 0
+    for n in range(64, 400):  # the first cut whose token count splits into whole rounds + a remainder
+        main_t, tail_t = split(int(cu[n]))
+        if tail_t:
+            break
+    assert tail_t and main_t % (64 * 256) == 0 and n >= 64, (main_t, tail_t, n)
+    ids, cu = ids[: cu[n]], cu[: n + 1]
+    mx = int(np.diff(cu).max())
+    assert mx > 128  # a long attention bucket exists: the shorter ones go to the side stream
+    args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), mx)
+    a = enc.encode_packed(*args).cpu().numpy()
+    b = enc.encode_packed(*args).cpu().numpy()
+    monkeypatch.setenv("ICREC_SIDE_STREAM", "0")
+    c = enc.encode_packed(*args).cpu().numpy()
+    monkeypatch.delenv("ICREC_SIDE_STREAM")
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    # the remainder's sequences encode to the same bits on their own (small-batch kernels on the caller's stream)
+    s0 = int(np.searchsorted(cu, main_t, side="right")) - 1
+    sub_cu = (cu[s0:] - cu[s0]).astype(np.int32)
+    sub = enc.encode_packed(torch.from_numpy(ids[cu[s0]:]).cuda(), torch.from_numpy(sub_cu).cuda(), int(np.diff(sub_cu).max()))
+    np.testing.assert_array_equal(sub.cpu().numpy(), a[s0:])
+    enc.close()
+
+
 @pytest.mark.parametrize("shape", ["short_batch", "long_batch", "single"])
 def test_workspace_contents_never_leak_into_results(minilm_weights, shape):
     """The caller-owned workspace may hold anything (here: NaN bit patterns everywhere) — every byte a kernel reads
