@@ -602,7 +602,9 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
 
 // Attention-output projection + residual + LayerNorm in one kernel (large batches): block = 64 tokens x all 384
 // features, K = 384.
-template <int D>
+// VAR (tools/ffn_bench.hip only; the product uses 0): 1 = accumulators start from zero (no residual rows in),
+// 2 = no LayerNorm / write-out (one dummy store per thread keeps the K loop alive)
+template <int D, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __restrict__ Ah,
                                                               const _Float16* __restrict__ Al, int T, int K,
                                                               const _Float16* __restrict__ Wp,
@@ -615,9 +617,22 @@ __global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __
     const int q = wave_uniform(threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     f32x16 acc[3][2];
-    wt_res_init_global(acc, q, bias, xh, xl, m0, T, smem + LNT_RED + q * LNT_TILE);
-    __syncthreads();  // the private tiles become the slab ring
-    wt_kloop<3, 2, D, false>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
+    if (!(VAR & 1)) {
+        wt_res_init_global(acc, q, bias, xh, xl, m0, T, smem + LNT_RED + q * LNT_TILE);
+        __syncthreads();  // the private tiles become the slab ring
+    }
+    wt_kloop<3, 2, D, (VAR & 1) != 0>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
+    if (VAR & 2) {
+        float sdum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sdum += acc[i][tt][e];
+        if (sdum == 123.456f) xh[m0 * 384 + threadIdx.x] = (_Float16)sdum;
+        return;
+    }
     wt_ln_out(acc, true, q, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); }, threadIdx.x);
     ICREC_STAMP(0, 30);
 }

@@ -223,6 +223,13 @@ int main(int argc, char** argv) {
         timeit("attn-out + LN wt_linear_ln<2>", [&] {
             hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, xh, xl, g, bn, 1e-12f);
         }, 2.0 * T * H * H);
+        if (T == 131072) {
+            std::vector<Cand> cs;
+            const int nb = (T + 63) / 64;
+#define CANDAO(V) cs.push_back({"attn-out + LN VAR=" #V " (1: no residual in, 2: no LN / write-out)", [=] { hipLaunchKernelGGL((wt_linear_ln_kernel<2, V>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, xh, xl, g, bn, 1e-12f); }, {}});
+            CANDAO(0) CANDAO(1) CANDAO(2) CANDAO(3)
+            compare(cs, 2.0 * T * H * H);
+        }
         reinit();
         hipDeviceSynchronize();
     }
