@@ -1449,8 +1449,11 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
     __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VT];
     __shared__ __attribute__((aligned(16))) _Float16 Vl[32 * VT];
     __shared__ float Ls[WAVES * 32];
-    static_assert(!RECOMP || WAVES * 2 * 32 * 32 <= 2 * NKT * 32 * 32, "the output tiles reuse the K planes");
-    _Float16* const Ob = Kbuf;  // per-wave output tile (hi | lo), long bucket only: aliases K after the second barrier
+    // Plane output (SPLIT): every wave parks its 32 x 32 output tile (hi | lo) on the K planes once all waves have left
+    // them (second barrier) and writes it out 16 B per lane - 4 store instructions instead of 32 two-byte ones.
+    constexpr bool OB = SPLIT;
+    static_assert(!OB || WAVES * 2 * 32 * 32 <= 2 * NKT * 32 * 32, "the output tiles reuse the K planes");
+    _Float16* const Ob = Kbuf;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
@@ -1514,7 +1517,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
     __syncthreads();
     ICREC_STAMP(0, 2);
     const bool active = qb < nkt;
-    if (!RECOMP && !active) return;  // idle wave (no barrier below)
+    if (!RECOMP && !OB && !active) return;  // idle wave (no barrier below)
 
     // raw scores S' = 256 S of key tile kt for this wave's 32 queries, keys beyond the sequence at -inf (only the one
     // tile that has any pays for the selects: uniform branch)
@@ -1603,6 +1606,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
         __syncthreads();  // every wave has left the K planes: they become the output tiles
         if (!active) return;
     } else {
+    if (active) {
     f32x16 sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -1648,8 +1652,13 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
     for (int kt = 0; kt < NKT; ++kt)
         if (kt < nkt) pv_tile(kt, sc[kt], o);
     }
+    if (OB) {
+        __syncthreads();  // every wave has left the K planes
+        if (!active) return;
+    }
+    }
     ICREC_STAMP(0, 4);
-    if (SPLIT && NKT >= 8) {
+    if (OB) {
         // park the wave's 32 x 32 output tile (hi and lo planes) in LDS row-major, then write it out 16 B
         // per lane: 4 store instructions instead of 32 two-byte ones
         _Float16* ob = Ob + wave * (2 * 32 * 32);
