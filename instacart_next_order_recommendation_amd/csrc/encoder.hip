@@ -1231,6 +1231,130 @@ __global__ __launch_bounds__(512, 2) void ffn_fused3_kernel(_Float16* __restrict
     }
 }
 
+// ---------------------------------------------------------------- QKV projection, activation-resident form (large batches)
+// out[T, N] = X . W^T + bias for a block of 64 tokens and ALL N = 1,152 features in one 8-wave workgroup, built like
+// the producer half of ffn_fused2_kernel: the block's 64 x 384 activation planes are loaded into LDS ONCE (96 KB; the
+// slab-ring form restreams them per 384-feature workgroup and pays a prologue, five slab barriers and an epilogue
+// barrier pair per 64 x 384 outputs), every wave walks whole feature tiles - wave w: tiles w, w + 8, ... (a SIMD
+// hosts waves s and s + 4 = 9 of the 36 tiles) - with K = 384 as 24 straight-line k-steps, the weight ring 8 k-steps
+// deep and running across tile boundaries, no workgroup barrier after the first.  Results leave through a private
+// per-wave LDS tile ([32 tokens][32 features] fp32, 144-B rows) as 16-B chunks: 128 B per token row per store.
+// Per output the MFMA chain is wt_kloop's: the same bits as wt_linear_kernel<3, 2, 2, 0>.
+constexpr int QKVR_STG_LD = 36;                                  // floats per staged row (+16 B)
+constexpr int QKVR_STG_BYTES = 32 * QKVR_STG_LD * 4;             // 4,608 B per wave
+constexpr int QKVR_LDS = FFN2_X_BYTES + 8 * QKVR_STG_BYTES;      // 135,168 B
+
+__global__ __launch_bounds__(512, 2) void qkv_resident_kernel(const _Float16* __restrict__ xh,
+                                                              const _Float16* __restrict__ xl, int T,
+                                                              const _Float16* __restrict__ Wp,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ out, int N) {
+    constexpr int KS1 = 24;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    char* const Xs = smem2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), r = lane & 31, h = lane >> 5;
+    float* const stg = reinterpret_cast<float*>(smem2 + FFN2_X_BYTES + wave * QKVR_STG_BYTES);
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int NT = N / 32;
+    // ---- the block's activation planes -> LDS, once (layout of ffn_fused2_kernel)
+    {
+        u32x4 vh[6], vl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            int64_t g = m0 + row;
+            g = g < T ? g : (int64_t)T - 1;
+            vh[i] = *reinterpret_cast<const u32x4*>(xh + g * 384 + c * 8);
+            vl[i] = *reinterpret_cast<const u32x4*>(xl + g * 384 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
+            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
+            *reinterpret_cast<u32x4*>(Xs + FFN2_XPLANE + pos) = vl[i];
+        }
+    }
+    const unsigned lo8 = lane * 8;
+    int xb[8][2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tok = tt * 32 + r;
+            xb[m][tt] = tok * 768 + (((2 * m) ^ h ^ (tok & 15)) << 4);
+        }
+    half8 wh[8][1], wl[8][1];
+    {
+        const _Float16* const wp0[1] = {Wp + wt_frag_off(wave, 0, KS1)};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
+    }
+    __syncthreads();  // X resident
+    // (Spreading a tile's write-out over the next tile's k-steps - one store per k-step instead of a burst of eight -
+    // was measured at the same speed with 256 instead of 190 VGPRs; running without any store is 72 us per launch
+    // faster: the 604 MB of fp32 QKV rows per launch are what the rest of the time buys.)
+    for (int nt = wave; nt < NT; nt += 8) {
+        const int nn = nt + 8 < NT ? nt + 8 : nt;  // past the last tile: re-read this one's fragments (never consumed)
+        const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
+        const _Float16* const wpn[1] = {Wp + wt_frag_off(nn, 0, KS1)};
+        f32x4 bv[4];  // loaded BEFORE the k-loop (vmcnt counts in order: behind the ring it would wait for the whole ring)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * g + 4 * h);
+        f32x16 S[1][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+        half8 fh[2][2], fl[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb[0][tt]);
+            fl[0][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + xb[0][tt]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            if (ks + 1 < KS1) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int pos = xb[(ks + 1) & 7][tt] + ((ks + 1) >> 3) * 256;
+                    fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
+                    fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
+                }
+            }
+            wt_mma<1, 2>(S, wh[ks & 7], wl[ks & 7], fh[ks & 1], fl[ks & 1]);
+            if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
+            else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
+            __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+        }
+        // ---- this tile out: [32 tokens][32 features] per pass through the wave's private LDS tile
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(S[0][tt][4 * g + j], WT_UNSCALE, bv[g][j]);
+                *reinterpret_cast<f32x4*>(stg + r * QKVR_STG_LD + 8 * g + 4 * h) = v;
+            }
+            lds_order();
+            f32x4 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = lane + 64 * k;
+                o[k] = *reinterpret_cast<const f32x4*>(stg + (f >> 3) * QKVR_STG_LD + (f & 7) * 4);
+            }
+            lds_order();  // the tile is free for the next pass before the stores are issued
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = lane + 64 * k;
+                const int64_t tok = m0 + tt * 32 + (f >> 3);
+                if (tok < T) *reinterpret_cast<f32x4*>(out + tok * N + nt * 32 + (f & 7) * 4) = o[k];
+            }
+        }
+    }
+}
+
 // W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int N, int K,
                                                            _Float16* __restrict__ out) {
@@ -2036,6 +2160,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     const char* side_env = getenv("ICREC_SIDE_STREAM");  // ICREC_SIDE_STREAM=0: the remainder's kernels stay on the caller's stream (A/B)
     const bool side_stream = !(side_env && side_env[0] == '0');
     const bool persist = fuse_env && fuse_env[0] == '3';
+    const char* qr_env = getenv("ICREC_QKV_RESIDENT");  // ICREC_QKV_RESIDENT=0: A/B switch to the slab-ring QKV kernel (same bits)
+    const bool qkv_res = !(qr_env && qr_env[0] == '0') && H == 384;
     const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
     Encoder::Side* sd = nullptr;
     if (x3 && side_stream && (T_tail || split_att))
@@ -2061,9 +2187,17 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // Token ranges: [0, T_main) goes through the batch kernels in whole rounds of one 64-token workgroup per
             // CU, a short remainder [T_main, T) through the small-batch kernels (same arithmetic, same bits) instead
             // of costing every batch kernel an extra, almost empty round.
-            auto qkv_stage = [&](int r0, int Tn, hipStream_t st) {
+            auto qkv_stage = [&](int r0, int Tn, hipStream_t st) -> int {
+                if (Tn > X3_SMALL_M && qkv_res) {  // activation-resident form: one 64-token workgroup per CU
+                    auto kern = qkv_resident_kernel;
+                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), QKVR_LDS)) return rc_;
+                    hipLaunchKernelGGL(kern, dim3((Tn + 63) / 64), dim3(512), QKVR_LDS, st, xh + (size_t)r0 * H,
+                                       xl + (size_t)r0 * H, Tn, L.Wqkv_p, L.bqkv, qkv + (size_t)r0 * 3 * H, 3 * H);
+                    return ICREC_OK;
+                }
                 launch_wt_linear<0>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv,
                                     qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
+                return ICREC_OK;
             };
             auto post_stage = [&](int r0, int Tn, hipStream_t st) -> int {
                 float* const t1r = t1 + (size_t)r0 * H;
@@ -2111,12 +2245,12 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     ICREC_HIP(hipEventRecord(sd->ev_main, st));
                     ICREC_HIP(hipStreamWaitEvent(ts, sd->ev_main, 0));
                 }
-                qkv_stage(T_main, T_tail, ts);
+                if (int rc_ = qkv_stage(T_main, T_tail, ts)) return rc_;
                 ICREC_HIP(hipEventRecord(sd->ev_qkv_tail, ts));
             } else if (T_tail) {
-                qkv_stage(T_main, T_tail, st);
+                if (int rc_ = qkv_stage(T_main, T_tail, st)) return rc_;
             }
-            qkv_stage(0, T_main, st);
+            if (int rc_ = qkv_stage(0, T_main, st)) return rc_;
             if (T_tail && use_side) ICREC_HIP(hipStreamWaitEvent(st, sd->ev_qkv_tail, 0));
             if (split_att && use_side) {
                 // the long bucket keeps one 8-wave workgroup per CU busy (LDS) with issue slots to spare: the shorter
