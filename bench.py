@@ -357,7 +357,6 @@ def main() -> None:
     if rank == 0 and world == 1 and args.workload == "49k7" and not args.no_latency:
         import tempfile
 
-        from instacart_next_order_recommendation_amd.encoder import pack_token_ids
         from instacart_next_order_recommendation_amd.model_io import NativeTokenizer
 
         vdir = Path(tempfile.mkdtemp(prefix="icrec_vocab_"))
@@ -368,10 +367,9 @@ def main() -> None:
 
         def text_step():
             t_a = time.perf_counter()
-            seqs = tok(texts)
+            ids_t, cu_t = tok.packed(texts)  # the product's form (SbertModel.encode_to_device): packed ids, no Python lists
             t_b = time.perf_counter()
-            ids_t, cu_t, mx_t = pack_token_ids(seqs)
-            e = enc.encode_packed(torch.from_numpy(ids_t).to(dev), torch.from_numpy(cu_t).to(dev), mx_t)
+            e = enc.encode_packed_host(ids_t, cu_t)
             i_t, s_t = search.search(e, TOP_K)
             i_t.cpu(); s_t.cpu()
             return t_b - t_a, int(cu_t[-1])
@@ -383,7 +381,22 @@ def main() -> None:
             dt, n_tok_text = text_step()
             tok_s += dt
         wall = time.perf_counter() - t_a
+        # the same steps through the product's two-deep pipeline (pipeline.py, Recommender.recommend_batches):
+        # batch i+1 is tokenised on a worker thread while the GPU works on batch i
+        from instacart_next_order_recommendation_amd.pipeline import pipelined_search
+
+        n_pipe = 8
+        list(pipelined_search(tok, enc, lambda e, k, ex: search.search(e, k), [texts] * 2, TOP_K))
+        t_p = time.perf_counter()
+        n_out = sum(r[0].shape[0] for r in pipelined_search(tok, enc, lambda e, k, ex: search.search(e, k),
+                                                            [texts] * n_pipe, TOP_K))
+        wall_p = time.perf_counter() - t_p
+        assert n_out == args.batch * n_pipe
         text_path = {"qps": args.batch * reps / wall, "ms_per_step": wall / reps * 1e3,
+                     "pipelined": {"qps": n_out / wall_p, "ms_per_step": wall_p / n_pipe * 1e3, "batches": n_pipe,
+                                   "note": "Recommender.recommend_batches / pipeline.py: tokenisation of batch i+1 on a "
+                                           "worker thread under the GPU work of batch i, results read back from pinned "
+                                           "buffers after the next launch"},
                      "tokenize_ms_per_step": tok_s / reps * 1e3, "tokens_per_step": n_tok_text,
                      "host_threads": "min(CPU quota, texts/64) worker threads inside icrec_tokenize", "host_cpus_visible": os.cpu_count(),
                      "mean_tokens_per_context": n_tok_text / args.batch,

@@ -133,6 +133,33 @@ class DeviceEncoder:
         main.wait_stream(self._side)
         return out
 
+    def encode_packed_host(self, ids: np.ndarray, cu: np.ndarray, max_tokens_per_call: int = 1 << 18) -> torch.Tensor:
+        """Host arrays in the packed form (ids int32[T], cu_seqlens int32[n+1], e.g. HostTokenizer.packed) ->
+        embeddings [n, hidden] on the device, in input order; split into calls of at most
+        `max_tokens_per_call` tokens like encode_ids."""
+        n = int(cu.shape[0]) - 1
+        out = torch.empty((n, self.shape.hidden), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        lens = np.diff(cu)
+        if (lens < 1).any():
+            raise ValueError("every sequence needs at least one token")
+        if int(lens.max()) > MAX_SEQ_LEN:
+            raise ValueError(f"sequence longer than max_seq_length={MAX_SEQ_LEN}; truncate on the host")
+        if int(ids.min()) < 0 or int(ids.max()) >= self.shape.vocab_size:
+            raise ValueError(f"token id out of range [0, {self.shape.vocab_size})")
+        start = 0
+        while start < n:
+            end = int(np.searchsorted(cu, cu[start] + max_tokens_per_call, side="right")) - 1
+            end = min(max(end, start + 1), n)
+            t0, t1 = int(cu[start]), int(cu[end])
+            cu_c = np.ascontiguousarray(cu[start:end + 1] - t0, dtype=np.int32)
+            self.encode_packed(torch.from_numpy(np.ascontiguousarray(ids[t0:t1])).to(self.device, non_blocking=True),
+                               torch.from_numpy(cu_c).to(self.device, non_blocking=True), int(lens[start:end].max()),
+                               out=out[start:end], cu_host=cu_c)
+            start = end
+        return out
+
     def encode_ids(self, seqs: Sequence[Sequence[int]], max_tokens_per_call: int = 1 << 18) -> torch.Tensor:
         """Host token-id lists -> embeddings [n, hidden] on the device, in input order.
         Long inputs are split into calls of at most `max_tokens_per_call` tokens."""

@@ -121,6 +121,9 @@ class SbertModel:
 
     def encode_to_device(self, texts: Sequence[str], tokens_per_call: int = 1 << 18) -> torch.Tensor:
         """Embeddings [n, 384] left on the GPU (serving path: no host round trip)."""
+        packed = getattr(self.tokenizer, "packed", None)
+        if packed is not None:
+            return self.encoder.encode_packed_host(*packed(texts), max_tokens_per_call=tokens_per_call)
         return self.encoder.encode_ids(self.tokenizer(texts), max_tokens_per_call=tokens_per_call)
 
     def encode(self, sentences, batch_size: int = 64, show_progress_bar: bool = False,
@@ -243,6 +246,25 @@ class Recommender:
         emb = self.model.encode_to_device(list(queries))
         idx, sc = self._rank(emb, top_k, ex)
         return [self._to_results(idx[i], sc[i]) for i in range(len(queries))]
+
+    def recommend_batches(self, batches, top_k: int = 10, exclude_product_ids=None):
+        """Generator over a stream of query batches: element j equals recommend_batch(batches[j], top_k,
+        exclude_product_ids[j]).  Batch j+1 is tokenised on a worker thread while the GPU works on batch j and
+        batch j is read back after batch j+1 has been launched (pipeline.py)."""
+        from .pipeline import pipelined_search
+
+        top_k = max(int(top_k), 1)
+        if top_k > _native.ICREC_MAX_K:
+            raise ValueError(f"top_k={top_k} exceeds the kernel limit {_native.ICREC_MAX_K} "
+                             "(the API schema allows at most 100)")
+        k = min(top_k, len(self.product_ids))
+
+        def exclude(j):
+            e = exclude_product_ids[j] if exclude_product_ids is not None else None
+            return [self._excluded_rows(x) for x in e] if e is not None and any(e) else None
+
+        for idx, sc in pipelined_search(self.model.tokenizer, self.model.encoder, self._index.search, batches, k, exclude):
+            yield [self._to_results(idx[i], sc[i]) for i in range(idx.shape[0])]
 
     def recommend_batch_timed(self, queries: Sequence[str], top_k: int = 10, exclude_product_ids=None):
         """recommend_batch plus (embedding ms incl. host tokenisation, similarity ms) from HIP events

@@ -191,3 +191,24 @@ def test_graph_path_ignores_rows_outside_the_sequence(world):
         cap.srch_ws.fill_(0xFF)
     got = rec.recommend(q, top_k=10)
     assert got == want and all(np.isfinite(s) for _, s in got)
+
+
+def test_recommend_batches_pipeline_equals_recommend_batch(world):
+    """recommend_batches() overlaps the host tokenisation of batch j+1 with the GPU work of batch j and reads batch j
+    back after batch j+1 has been launched: every batch must equal recommend_batch() on the same inputs, bit for bit
+    (same launches, one stream, in order) - with exclusions, ragged batch sizes and an empty batch in the stream."""
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.recommender import Recommender
+
+    rec = Recommender(world["model_dir"], world["corpus_path"])
+    qs = syn.synthetic_user_contexts(37, seed=21)
+    batches = [qs[:8], qs[8:9], [], qs[9:30], qs[30:]]
+    excl = [[set(rec.product_ids[:20]) if i % 3 == 0 else None for i in range(len(b))] for b in batches]
+    got = list(rec.recommend_batches(batches, top_k=7, exclude_product_ids=excl))
+    assert len(got) == len(batches)
+    for b, e, g in zip(batches, excl, got):
+        assert g == rec.recommend_batch(b, 7, e)
+    # a generator input and no exclusions
+    got2 = list(rec.recommend_batches((b for b in batches), top_k=7))
+    assert [len(g) for g in got2] == [len(b) for b in batches]
+    assert got2[3] == rec.recommend_batch(batches[3], 7)
