@@ -8,6 +8,7 @@
 // of /root/reference/src/inference/serve_recommendations.py.
 #include "common.h"
 #include "gemm_x3.h"
+#include "wt_gemm.h"
 
 namespace icrec {
 
@@ -66,10 +67,17 @@ __global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restr
 // candidate queue slots per query between two list merges (more when few queries share the LDS)
 template <class Cfg> struct QCap { static constexpr int V = Cfg::BN <= 32 ? 64 : 16; };
 
-template <class Cfg, bool X3 = false>
+// Resident filter pass (PMODE 3): the query tile's two activation planes, [64 queries][384] halfs each, live in LDS
+// for the whole block in the layout of the encoder's fused kernels (768-B rows as three XOR-swizzled 256-B sub-rows).
+constexpr int RES_XPLANE = 64 * 768;
+constexpr int RES_X_BYTES = 2 * RES_XPLANE;
+constexpr int RES_KS = 24;  // k-steps of 16: the resident pass is built for dim = 384
+
+template <class Cfg, int MODE = 0>  // MODE: 0 fp32 tiles, 2 f16 hi/lo planes staged per tile, 3 resident query planes
 struct SearchSmem {
     // operand staging: fp32 tiles (common.h) or the f16 hi/lo planes of the filter pass (gemm_x3.h)
-    static constexpr size_t GEMM = X3 ? (size_t)(2 * Cfg::BM + 2 * Cfg::BN) * HLD * 2 : (size_t)Cfg::LDS_FLOATS * 4;
+    static constexpr size_t GEMM = MODE == 3 ? (size_t)RES_X_BYTES
+                                   : MODE == 2 ? (size_t)(2 * Cfg::BM + 2 * Cfg::BN) * HLD * 2 : (size_t)Cfg::LDS_FLOATS * 4;
     // dynamic LDS carve (all offsets multiples of 16 B)
     static __host__ __device__ size_t bytes(int k) {
         return GEMM + (size_t)Cfg::BN * (8 /*thr*/ + 4 /*cnt*/) + 16 /*flags*/ +
@@ -154,6 +162,12 @@ __device__ __forceinline__ void merge_queue2(u64* list, const u64* queue, int qc
 // 2: the FILTER pass of ICREC_ROWS_F32_FILTER — rows and queries as f16 hi/lo planes (P/P2, Qn/Q2), scores from
 //    three f16 MFMAs per product (gemm_x3.h): within ~1e-7 of the exact chain at 5x its MFMA rate, NOT bit-exact;
 //    its lists only nominate candidates for verify_kernel.
+// 3: the RESIDENT form of the filter pass (dim = 384, catalogs up to RES_MAX_ROWS): P = the rows as packed weight
+//    fragments (wt_gemm.h: the 1 KB one wave feeds to one MFMA is contiguous), Qn/Q2 = the queries' activation planes.
+//    The block's 64 queries are loaded into LDS ONCE and stay there for all its row tiles; every wave owns one
+//    32-row tile of each 256-row round and streams its fragments L2 -> registers through an 8-deep ring that runs
+//    across rounds (the next round's first fragments land under the selection): no operand staging barriers at all -
+//    PMODE 2 re-stages both operands through LDS for every 128-row tile (two barriers per 64-deep slab).
 // run_flag != NULL: the whole grid exits unless *run_flag != 0 (the exact pass behind a filter pass).
 template <class Cfg, bool EMIT, int PMODE>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     constexpr bool P16 = PMODE == 1;
     float* As = reinterpret_cast<float*>(smem_raw);
     float* Bs = As + Cfg::BM * LDK;
-    u64* thr = reinterpret_cast<u64*>(smem_raw + SearchSmem<Cfg, PMODE == 2>::GEMM);
+    u64* thr = reinterpret_cast<u64*>(smem_raw + SearchSmem<Cfg, PMODE >= 2 ? PMODE : 0>::GEMM);
     int* cnt = reinterpret_cast<int*>(thr + Cfg::BN);
     int* flags = cnt + Cfg::BN;  // [0],[1]: alternating "some candidate did not fit" flags
     u64* list = reinterpret_cast<u64*>(flags + 4);
@@ -204,9 +218,84 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     TileRegs<Cfg, P16> pre;
     f32x16 acc[Cfg::TM][Cfg::TN];
 
+    // ---- PMODE 3: query planes -> LDS (once), weight ring of the first round
+    half8 rwh[8][1], rwl[8][1];
+    int xb0[2] = {0, 0};
+    const unsigned lo8 = lane * 8;
+    if constexpr (PMODE == 3) {
+        static_assert(PMODE != 3 || (Cfg::TM == 1 && Cfg::TN == 2 && Cfg::WAVES_N == 1 && Cfg::WAVES_M == 8),
+                      "resident pass: 8 waves x (1 row tile x 2 query tiles)");
+        const _Float16* qh = static_cast<const _Float16*>(Qn);
+        const _Float16* ql = static_cast<const _Float16*>(Q2);
+        char* const Xs = smem_raw;
+        u32x4 vh[6], vl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            const int64_t g = (int64_t)(q0 + row) * 384 + c * 8;  // Qpad is a multiple of 64: every row exists
+            vh[i] = *reinterpret_cast<const u32x4*>(qh + g);
+            vl[i] = *reinterpret_cast<const u32x4*>(ql + g);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
+            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
+            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
+            *reinterpret_cast<u32x4*>(Xs + RES_XPLANE + pos) = vl[i];
+        }
+        // this lane's fragment of query tile tt at k-step ks: xb0[tt] ^ ((ks & 7) << 5), + 256 (ks >> 3)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tok = tt * 32 + (lane & 31);
+            xb0[tt] = tok * 768 + (((lane >> 5) ^ (tok & 15)) << 4);
+        }
+        if (t_begin < t_end) {
+            const _Float16* const wp0[1] = {static_cast<const _Float16*>(P) + wt_frag_off(t_begin * 8 + wave, 0, RES_KS)};
+#pragma unroll
+            for (int d = 0; d < 8; ++d) w_load<1>(rwh[d], rwl[d], wp0, d, lo8);
+        }
+        __syncthreads();  // queries resident
+    }
+
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int64_t row0 = (int64_t)tile * Cfg::BM;
-        if (PMODE == 2) {
+        if constexpr (PMODE == 3) {
+            const char* const Xs = smem_raw;
+            const int rt = tile * 8 + wave;
+            const int rn = tile + 1 < t_end ? rt + 8 : rt;  // past the block's last round: re-read (never consumed)
+            const _Float16* const wp1[1] = {static_cast<const _Float16*>(P) + wt_frag_off(rt, 0, RES_KS)};
+            const _Float16* const wpn[1] = {static_cast<const _Float16*>(P) + wt_frag_off(rn, 0, RES_KS)};
+            f32x16 S[1][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+            half8 fh[2][2], fl[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb0[tt]);
+                fl[0][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + xb0[tt]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < RES_KS; ++ks) {
+                if (ks + 1 < RES_KS) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int pos = (xb0[tt] ^ (((ks + 1) & 7) << 5)) + ((ks + 1) >> 3) * 256;
+                        fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
+                        fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + pos);
+                    }
+                }
+                wt_mma<1, 2>(S, rwh[ks & 7], rwl[ks & 7], fh[ks & 1], fl[ks & 1]);
+                if (ks + 8 < RES_KS) w_load<1>(rwh[ks & 7], rwl[ks & 7], wp1, ks + 8, lo8);
+                else w_load<1>(rwh[ks & 7], rwl[ks & 7], wpn, ks + 8 - RES_KS, lo8);
+                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[0][j][e] = S[0][j][e] * WT_UNSCALE;
+        } else if (PMODE == 2) {
             f32x16 a0[Cfg::TM][Cfg::TN], a1[Cfg::TM][Cfg::TN];
             tile_gemm_h<Cfg>(a0, a1, static_cast<const _Float16*>(P), static_cast<const _Float16*>(P2), row0, N,
                              static_cast<const _Float16*>(Qn), static_cast<const _Float16*>(Q2), q0, Qpad, K,
@@ -559,6 +648,51 @@ __global__ __launch_bounds__(256) void split_queries_kernel(const void* __restri
     }
 }
 
+// Resident filter pass: the (normalised) catalog rows as packed weight fragments - fragment (row tile rt, k-step ks,
+// plane) = 512 halfs at ((rt * KS + ks) * 2 + plane) * 512, lane l = (h << 5 | r) holds row rt*32 + r, k = 16 ks + 8 h
+// .. +7, hi = f16(1024 x), lo = f16(1024 x - hi) (wt_gemm.h) - once at index creation; rows past n_rows are zero.
+template <bool SRC16>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const void* __restrict__ src, int64_t n_rows, int K, int64_t n_frag,
+                                                        _Float16* __restrict__ out) {
+    const int KS = K / 16;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < n_frag * 64; id += (int64_t)gridDim.x * 256) {
+        const int64_t fr = id >> 6;
+        const int lane = (int)(id & 63), r = lane & 31, h = lane >> 5;
+        const int64_t rt = fr / KS;
+        const int ks = (int)(fr % KS);
+        const int64_t row = rt * 32 + r;
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.0f;
+            if (row < n_rows) {
+                const size_t at = (size_t)row * K + ks * 16 + 8 * h + j;
+                v = SRC16 ? __uint_as_float((unsigned)static_cast<const uint16_t*>(src)[at] << 16)
+                          : static_cast<const float*>(src)[at];
+            }
+            _Float16 a, b;
+            split_scaled(v, WT_SW, a, b);
+            hi[j] = a;
+            lo[j] = b;
+        }
+        *reinterpret_cast<half8*>(out + fr * (2 * WT_FRAG) + lane * 8) = hi;
+        *reinterpret_cast<half8*>(out + fr * (2 * WT_FRAG) + WT_FRAG + lane * 8) = lo;
+    }
+}
+
+// queries -> the engine's activation planes (hi/lo of 16 x, wt_gemm.h: split_act4), row-major [Qpad][K]; clears the flag
+__global__ __launch_bounds__(256) void split_queries_act_kernel(const float* __restrict__ src, size_t n4, _Float16* __restrict__ hi,
+                                                                _Float16* __restrict__ lo, int* __restrict__ flag) {
+    if (flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        half4 a, b;
+        split_act4(v, a, b);
+        *reinterpret_cast<half4*>(hi + 4 * i) = a;
+        *reinterpret_cast<half4*>(lo + 4 * i) = b;
+    }
+}
+
 // Exact re-scoring of the filter pass's candidates.  cand[q][0..kp): the kp best (approximate score, row) keys of
 // query q, sorted; one wavefront per query, two candidates per lane.  Every candidate gets the exact k-ascending
 // fp32 fmaf chain (the oracle's arithmetic) from the fp32 rows, candidates are ranked by (exact score desc, row asc)
@@ -699,6 +833,8 @@ struct Index {
     void* rows = nullptr;  // normalised [n_rows, dim], fp32 or bf16 bits
     _Float16* plane_hi = nullptr;  // ICREC_ROWS_F32_FILTER: f16 hi/lo planes of `rows` for the filter pass
     _Float16* plane_lo = nullptr;
+    _Float16* frag = nullptr;      // resident filter pass (dim 384, <= RES_MAX_ROWS rows): the rows as packed fragments
+    int64_t frag_row_tiles = 0;    // 32-row tiles in `frag` (a multiple of 8: whole 256-row rounds)
     int storage = ICREC_ROWS_F32;
     int64_t n_rows = 0;
     int dim = 0;
@@ -713,6 +849,12 @@ typedef TileCfg<2, 2, 2, 2> CfgBig;    // 128 rows x 128 queries
 typedef TileCfg<4, 1, 2, 2> CfgMid;    // 256 rows x  64 queries
 typedef TileCfg<4, 1, 2, 1> CfgSmall;  // 256 rows x  32 queries
 typedef TileCfg<2, 2, 2, 1> CfgFilter;  // 128 rows x  64 queries, f16 planes (filter pass)
+typedef TileCfg<8, 1, 1, 2> CfgRes;     // 256 rows x  64 queries per round, 8 waves (resident filter pass)
+// Catalogs up to this many rows get the packed fragments of the resident filter pass INSTEAD of the row-major planes
+// (same bytes).  Every 64-query block streams the whole shard from L2 / Infinity Cache, so the form pays while the
+// fragments (1,536 B per row) stay cache-resident: 76 MB at 49,688 rows; larger shards keep the staged pass, whose
+// 128-row x 64-query tiles read each row once per 64 queries from HBM just the same but need no second layout.
+constexpr int64_t RES_MAX_ROWS = 131072;
 
 // Filter + verify (ICREC_ROWS_F32_FILTER): batches of at least FILTER_MIN_Q queries are ranked by the f16x3 filter
 // pass with FILTER_SLACK extra list entries, then verified exactly.  FILTER_EPS bounds |filter score - exact score|
@@ -817,7 +959,7 @@ static int launch_search(const Index* ix, const Plan& p, const float* qn, int Q,
 // Workspace of the filter + verify path: [qn fp32 | q hi | q lo | flag | candidate keys | partial lists (filter pass,
 // then reused by the guarded exact pass)].
 struct FilterPlan {
-    bool use;
+    bool use, resident;
     int kp, Qpad, n_qtiles, n_row_tiles, tiles_per_chunk, n_chunks;
     size_t smem, off_qh, off_ql, off_flag, off_cand, off_partial, ws_total;
 };
@@ -825,18 +967,24 @@ struct FilterPlan {
 static FilterPlan make_filter_plan(const Index* ix, int Q, int k, const Plan& exact) {
     FilterPlan f;
     f.kp = filter_list_len(k);
-    f.use = ix->plane_hi != nullptr && Q >= FILTER_MIN_Q && f.kp <= ICREC_MAX_K;
+    f.resident = ix->frag != nullptr;
+    f.use = (ix->plane_hi != nullptr || f.resident) && Q >= FILTER_MIN_Q && f.kp <= ICREC_MAX_K;
+    // resident form: the query planes leave 64 KB of LDS for the lists (k <= 92); longer lists take the exact search,
+    // which is the faster one there anyway (measured at 49,688 rows, Q = 1,024, k = 100: staged filter 2.5 ms, exact 1.5 ms)
+    if (f.resident && SearchSmem<CfgRes, 3>::bytes(f.kp) > 160 * 1024) f.use = false;
     if (!f.use) { f.ws_total = 0; return f; }
-    f.n_qtiles = (Q + CfgFilter::BN - 1) / CfgFilter::BN;
+    const int BMf = f.resident ? CfgRes::BM : CfgFilter::BM;
+    f.n_qtiles = (Q + CfgFilter::BN - 1) / CfgFilter::BN;  // 64 queries per tile in both forms
     f.Qpad = f.n_qtiles * CfgFilter::BN;
-    f.n_row_tiles = (int)((ix->n_rows + CfgFilter::BM - 1) / CfgFilter::BM);
-    int want_chunks = (2 * ix->n_cu) / f.n_qtiles;
+    f.n_row_tiles = (int)((ix->n_rows + BMf - 1) / BMf);
+    // staged form: two 4-wave blocks per CU; resident form: one 8-wave block per CU (its query planes take 96 KB)
+    int want_chunks = ((f.resident ? 1 : 2) * ix->n_cu) / f.n_qtiles;
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > 256) want_chunks = 256;
     if (want_chunks > f.n_row_tiles) want_chunks = f.n_row_tiles;
     f.tiles_per_chunk = (f.n_row_tiles + want_chunks - 1) / want_chunks;
     f.n_chunks = (f.n_row_tiles + f.tiles_per_chunk - 1) / f.tiles_per_chunk;
-    f.smem = SearchSmem<CfgFilter, true>::bytes(f.kp);
+    f.smem = f.resident ? SearchSmem<CfgRes, 3>::bytes(f.kp) : SearchSmem<CfgFilter, 2>::bytes(f.kp);
     const int qpad_max = f.Qpad > exact.Qpad ? f.Qpad : exact.Qpad;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     f.off_qh = up((size_t)qpad_max * ix->dim * 4);
@@ -868,9 +1016,19 @@ static int run_search_filtered(Index* ix, const FilterPlan& f, const Plan& ex, c
     hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((qpad_max + 3) / 4), dim3(256), 0, st, q, (void*)qn, (int64_t)Q,
                        (int64_t)qpad_max, ix->dim, 1e-12f, 0);
     const size_t nq = (size_t)f.Qpad * ix->dim;
-    hipLaunchKernelGGL(split_queries_kernel<false>, dim3((unsigned)((nq + 255) / 256 < 1024 ? (nq + 255) / 256 : 1024)),
-                       dim3(256), 0, st, (const void*)qn, nq, qh, ql, flag);
-    {
+    if (f.resident) {
+        hipLaunchKernelGGL(split_queries_act_kernel, dim3((unsigned)((nq / 4 + 255) / 256 < 1024 ? (nq / 4 + 255) / 256 : 1024)),
+                           dim3(256), 0, st, (const float*)qn, nq / 4, qh, ql, flag);
+        auto kern = search_kernel<CfgRes, false, 3>;
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc_;
+        ScopedTimer tm(T_SEARCH_KERNEL, st);
+        hipLaunchKernelGGL(kern, dim3(f.n_chunks * f.n_qtiles), dim3(CfgRes::THREADS), f.smem, st,
+                           (const void*)ix->frag, (const void*)nullptr, ix->n_rows, ix->dim, (const void*)qh,
+                           (const void*)ql, f.Qpad, Q, f.kp, ei, eo, (uint32_t)ix->row_offset, f.n_row_tiles,
+                           f.tiles_per_chunk, f.n_qtiles, partial, (float*)nullptr, (const int*)nullptr);
+    } else {
+        hipLaunchKernelGGL(split_queries_kernel<false>, dim3((unsigned)((nq + 255) / 256 < 1024 ? (nq + 255) / 256 : 1024)),
+                           dim3(256), 0, st, (const void*)qn, nq, qh, ql, flag);
         auto kern = search_kernel<CfgFilter, false, 2>;
         if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc_;
         ScopedTimer tm(T_SEARCH_KERNEL, st);
@@ -913,7 +1071,7 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     ICREC_REQUIRE(Q >= 1, "icrec_search: n_queries must be >= 1 (got %d)", Q);
     ICREC_REQUIRE(k >= 1 && k <= ICREC_MAX_K, "icrec_search: k must be in [1, %d] (got %d)", ICREC_MAX_K, k);
     ICREC_REQUIRE((ei == nullptr) == (eo == nullptr), "icrec_search: excl_idx and excl_off must both be set or both NULL");
-    if (scores_out == nullptr && ix->plane_hi != nullptr) {
+    if (scores_out == nullptr && (ix->plane_hi != nullptr || ix->frag != nullptr)) {
         const Plan ex = make_plan(ix, Q, k, false);
         const FilterPlan f = make_filter_plan(ix, Q, k, ex);
         if (f.use) {
@@ -1079,7 +1237,22 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     else
         hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
     ICREC_HIP(hipGetLastError());
-    if (with_planes) {
+    if (with_planes && dim == 16 * RES_KS && n_rows <= RES_MAX_ROWS && !(getenv("ICREC_FILTER_RESIDENT") && getenv("ICREC_FILTER_RESIDENT")[0] == '0')) {
+        // resident filter pass: packed fragments instead of the row-major planes
+        ix->frag_row_tiles = ((n_rows + CfgRes::BM - 1) / CfgRes::BM) * 8;
+        const int64_t n_frag = ix->frag_row_tiles * RES_KS;
+        if (hipMalloc(&ix->frag, (size_t)n_frag * 2 * WT_FRAG * sizeof(_Float16)) != hipSuccess) {
+            hipFree(ix->rows);
+            delete ix;
+            set_error("icrec_index_create: hipMalloc of the filter fragments (%zu bytes) failed", (size_t)n_frag * 2 * WT_FRAG * 2);
+            return ICREC_ENOMEM;
+        }
+        if (rows16)  // fragments of the ROUNDED rows: the filter then approximates exactly what the exact pass computes
+            hipLaunchKernelGGL(pack_rows_kernel<true>, dim3(4096), dim3(256), 0, 0, (const void*)ix->rows, n_rows, dim, n_frag, ix->frag);
+        else
+            hipLaunchKernelGGL(pack_rows_kernel<false>, dim3(4096), dim3(256), 0, 0, (const void*)ix->rows, n_rows, dim, n_frag, ix->frag);
+        ICREC_HIP(hipGetLastError());
+    } else if (with_planes) {
         const size_t n = (size_t)n_rows * dim;
         hipError_t e1 = hipMalloc(&ix->plane_hi, n * 2), e2 = hipMalloc(&ix->plane_lo, n * 2);
         if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1117,6 +1290,7 @@ int icrec_index_destroy(icrec_index* h) {
     hipFree(ix->rows);
     hipFree(ix->plane_hi);
     hipFree(ix->plane_lo);
+    hipFree(ix->frag);
     delete ix;
     return ICREC_OK;
 }

@@ -147,7 +147,10 @@ class SbertModel:
                 self._encoder_no_flag = DeviceEncoder(self._weights, replace(self.shape, n_normalize=self.shape.n_normalize - 1),
                                                       self.device, gemm_mode=self.encoder.gemm_mode)
             enc = self._encoder_no_flag
-        emb = enc.encode_ids(self.tokenizer(texts), max_tokens_per_call=max(int(batch_size), 1) * 4096).cpu().numpy()
+        packed = getattr(self.tokenizer, "packed", None)
+        per_call = max(int(batch_size), 1) * 4096
+        emb = (enc.encode_packed_host(*packed(texts), max_tokens_per_call=per_call) if packed is not None
+               else enc.encode_ids(self.tokenizer(texts), max_tokens_per_call=per_call)).cpu().numpy()
         return emb[0] if single else emb
 
 
@@ -275,11 +278,12 @@ class Recommender:
         if exclude_product_ids is not None and any(exclude_product_ids):
             ex = [self._excluded_rows(e) for e in exclude_product_ids]
         t0 = time.time()
-        ids = self.model.tokenizer(list(queries))
+        packed = getattr(self.model.tokenizer, "packed", None)
+        ids = packed(list(queries)) if packed is not None else self.model.tokenizer(list(queries))
         tok_ms = (time.time() - t0) * 1000
         stream = torch.cuda.current_stream(self.device)
         e0.record(stream)
-        emb = self.model.encoder.encode_ids(ids)
+        emb = self.model.encoder.encode_packed_host(*ids) if packed is not None else self.model.encoder.encode_ids(ids)
         e1.record(stream)
         if top_k > _native.ICREC_MAX_K:
             raise ValueError(f"top_k={top_k} exceeds the kernel limit {_native.ICREC_MAX_K}")

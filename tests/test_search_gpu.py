@@ -295,9 +295,13 @@ def test_merge_many_lists(torch_cuda):
 # ---------------------------------------------------------------- filter + verify (ICREC_ROWS_F32_FILTER)
 @pytest.mark.parametrize("nq,k,n", [(256, 20, 1000), (300, 50, 3000), (513, 20, 5000), (384, 100, 2049), (257, 1, 777),
                                       (260, 116, 4000), (256, 120, 3000), (70, 20, 3000)])
-def test_filter_index_is_bit_identical_to_exact(torch_cuda, nq, k, n):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_filter_index_is_bit_identical_to_exact(torch_cuda, monkeypatch, resident, nq, k, n):
     """f16x3 filter pass + exact verification returns the exact search's bits (indices, scores), with
-    exclusions; k + slack > 128 and batches under 256 queries (last two cases) silently take the exact path."""
+    exclusions; k + slack > 128 and batches under 256 queries (last two cases) silently take the exact path.
+    Both forms of the filter pass: resident (query planes in LDS, rows as packed fragments - the default up to
+    131,072 rows) and staged (ICREC_FILTER_RESIDENT=0 at index creation: row-major planes, both operands through LDS)."""
+    monkeypatch.setenv("ICREC_FILTER_RESIDENT", resident)
     rng = np.random.default_rng(nq * 31 + k)
     P = rng.standard_normal((n, 384)).astype(np.float32)
     q = rng.standard_normal((nq, 384)).astype(np.float32)
@@ -382,9 +386,12 @@ def test_filter_full_catalog_batch(torch_cuda):
 
 
 @pytest.mark.parametrize("nq,k,n", [(256, 20, 3000), (300, 50, 5000)])
-def test_bf16_filter_index_is_bit_identical_to_bf16_exact(torch_cuda, nq, k, n):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_bf16_filter_index_is_bit_identical_to_bf16_exact(torch_cuda, monkeypatch, resident, nq, k, n):
     """ICREC_ROWS_BF16_FILTER: filter planes built from the ROUNDED rows, verification and fallback on the bf16 rows
-    themselves — same bits as storage="bf16" and as the oracle's bf16 search, incl. a duplicate-row fallback."""
+    themselves — same bits as storage="bf16" and as the oracle's bf16 search, incl. a duplicate-row fallback;
+    resident and staged form of the filter pass."""
+    monkeypatch.setenv("ICREC_FILTER_RESIDENT", resident)
     rng = np.random.default_rng(nq + k)
     P = rng.standard_normal((n, 384)).astype(np.float32)
     P[rng.choice(n, 200, replace=False)] = P[1]  # 200 identical rows: some queries cannot be proven
