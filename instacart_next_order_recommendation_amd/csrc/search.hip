@@ -850,11 +850,12 @@ typedef TileCfg<4, 1, 2, 2> CfgMid;    // 256 rows x  64 queries
 typedef TileCfg<4, 1, 2, 1> CfgSmall;  // 256 rows x  32 queries
 typedef TileCfg<2, 2, 2, 1> CfgFilter;  // 128 rows x  64 queries, f16 planes (filter pass)
 typedef TileCfg<8, 1, 1, 2> CfgRes;     // 256 rows x  64 queries per round, 8 waves (resident filter pass)
-// Catalogs up to this many rows get the packed fragments of the resident filter pass INSTEAD of the row-major planes
-// (same bytes).  Every 64-query block streams the whole shard from L2 / Infinity Cache, so the form pays while the
-// fragments (1,536 B per row) stay cache-resident: 76 MB at 49,688 rows; larger shards keep the staged pass, whose
-// 128-row x 64-query tiles read each row once per 64 queries from HBM just the same but need no second layout.
-constexpr int64_t RES_MAX_ROWS = 131072;
+// Filter storages of dimension 384 keep the rows as the packed fragments of the resident filter pass INSTEAD of the
+// row-major planes (same bytes).  Every 64-query block streams its chunk of the shard through L2; the blocks of a
+// chunk sit on one XCD (xcd_remap) and walk it in step, so HBM still sees each fragment about once.  Measured against
+// the staged pass (same box, top-20): 49,688 rows x 1,024 queries 0.26 vs 0.39 ms; 2 M rows 4.5 vs 6.5 ms; 10 M rows
+// 19.6 vs 30.1 ms, x 4,096 queries 74 vs 124 ms (425 TF-equivalent = 0.51 of the 3-pass f16 roof).
+constexpr int64_t RES_MAX_ROWS = (int64_t)1 << 40;  // no limit (ICREC_FILTER_RESIDENT=<n> sets one, =0 forces the staged form)
 
 // Filter + verify (ICREC_ROWS_F32_FILTER): batches of at least FILTER_MIN_Q queries are ranked by the f16x3 filter
 // pass with FILTER_SLACK extra list entries, then verified exactly.  FILTER_EPS bounds |filter score - exact score|
@@ -1237,7 +1238,9 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     else
         hipLaunchKernelGGL(normalize_rows_kernel<false>, grid, dim3(256), 0, 0, rows_dev, ix->rows, n_rows, n_rows, dim, 1e-12f);
     ICREC_HIP(hipGetLastError());
-    if (with_planes && dim == 16 * RES_KS && n_rows <= RES_MAX_ROWS && !(getenv("ICREC_FILTER_RESIDENT") && getenv("ICREC_FILTER_RESIDENT")[0] == '0')) {
+    const char* res_env = getenv("ICREC_FILTER_RESIDENT");  // "0": staged form; a number > 1: row limit of the resident form (A/B)
+    const int64_t res_max = res_env && atoll(res_env) > 1 ? atoll(res_env) : RES_MAX_ROWS;
+    if (with_planes && dim == 16 * RES_KS && n_rows <= res_max && !(res_env && res_env[0] == '0' && res_env[1] == 0)) {
         // resident filter pass: packed fragments instead of the row-major planes
         ix->frag_row_tiles = ((n_rows + CfgRes::BM - 1) / CfgRes::BM) * 8;
         const int64_t n_frag = ix->frag_row_tiles * RES_KS;

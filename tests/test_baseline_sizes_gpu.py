@@ -90,9 +90,10 @@ def _device_catalog(torch, n_rows: int, seed: int):
     return rows
 
 
-def test_2m_row_bf16_catalog_vs_oracle(cuda):
-    """2,000,000 x 384 bf16 rows (and bf16 + filter planes): Q in {1, 64, 1024}; a sample of queries is checked
-    bit for bit against oracle.search(storage="bf16") over the same fp32 input rows."""
+def test_2m_row_bf16_catalog_vs_oracle(cuda, monkeypatch):
+    """2,000,000 x 384 bf16 rows (and bf16 + filter: the resident form with the rows as packed fragments, and the
+    staged form with row-major planes): Q in {1, 64, 1024}; a sample of queries is checked bit for bit against
+    oracle.search(storage="bf16") over the same fp32 input rows."""
     torch = cuda
     from instacart_next_order_recommendation_amd.search import DeviceIndex
     from oracle import oracle
@@ -105,7 +106,8 @@ def test_2m_row_bf16_catalog_vs_oracle(cuda):
     oracle.set_threads(oracle.usable_cpus())
     sample = [0, 63, 500, 1023]
     want_i, want_s = oracle.search(q_all[sample].cpu().numpy(), P_host, 20, None, storage="bf16")
-    for storage in ("bf16", "bf16+filter"):
+    for storage, resident in (("bf16", "1"), ("bf16+filter", "1"), ("bf16+filter", "0")):
+        monkeypatch.setenv("ICREC_FILTER_RESIDENT", resident)
         ix = DeviceIndex(rows, storage=storage)
         for nq in (1, 64, 1024):
             idx, sc = ix.search(q_all[:nq], 20)

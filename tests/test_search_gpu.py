@@ -299,8 +299,7 @@ def test_merge_many_lists(torch_cuda):
 def test_filter_index_is_bit_identical_to_exact(torch_cuda, monkeypatch, resident, nq, k, n):
     """f16x3 filter pass + exact verification returns the exact search's bits (indices, scores), with
     exclusions; k + slack > 128 and batches under 256 queries (last two cases) silently take the exact path.
-    Both forms of the filter pass: resident (query planes in LDS, rows as packed fragments - the default up to
-    131,072 rows) and staged (ICREC_FILTER_RESIDENT=0 at index creation: row-major planes, both operands through LDS)."""
+    Both forms of the filter pass: resident (query planes in LDS, rows as packed fragments - the default) and staged (ICREC_FILTER_RESIDENT=0 at index creation: row-major planes, both operands through LDS)."""
     monkeypatch.setenv("ICREC_FILTER_RESIDENT", resident)
     rng = np.random.default_rng(nq * 31 + k)
     P = rng.standard_normal((n, 384)).astype(np.float32)
