@@ -144,6 +144,14 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
                             "(tools/mfma_peak.hip, profiles/r02_mfma_sustained_rate.txt: the clock falls under matrix load), i.e. "
                             "671 TFLOP/s of f16x3 products: frac_of_measured_mfma_ceiling prices the launch against that",
             "frac_of_measured_mfma_ceiling": achieved / (2012.0 / 3.0),
+            # what actually sets the time: every 64-token workgroup pulls the layer's W1/W2 fragments
+            # (4.72 MB) + its planes through its vector L1; the chip delivers ~12 TB/s of such requests
+            "l2_stream": {"bytes_per_launch": (tokens // 64) * (2 * 2 * 1536 * 384 * 2 + 64 * 384 * 4 + 3 * 1024),
+                          "TBps_at_this_launch_time": ((tokens // 64) * (2 * 2 * 1536 * 384 * 2 + 64 * 384 * 4 + 3 * 1024)) / (ms * 1e-3) / 1e12
+                          if ms > 0 else None,
+                          "note": "L2 -> L1 requests per launch (PMC TCP_TCC_READ_REQ x 128 B: 10.2 GB, "
+                                  "profiles/r02_pmc_l2_stream.txt); the resident QKV kernel (4.1 GB / 0.33 ms) and the resident "
+                                  "search pass at 10 M rows (246 GB / 19.6 ms) run at the same 12-12.5 TB/s"},
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
 
