@@ -1529,6 +1529,36 @@ __global__ __launch_bounds__(WAVES * 64) void attention_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------- dispatch order of the attention workgroups
+// order[0 .. n_seqs) = the sequences sorted by length, longest first (counting sort over the 256 possible lengths;
+// the order inside one length is whatever the atomics give - the workgroups are independent, results do not depend
+// on it).  The attention launches map workgroup b to sequence order[b / heads]: each bucket's workgroups are then
+// dispatched longest-first with the other buckets' (empty) workgroups behind them instead of in between, so a launch
+// does not end on a few 8-tile sequences that started last.
+__global__ __launch_bounds__(1024) void seq_order_kernel(const int32_t* __restrict__ cu, int n_seqs,
+                                                         int32_t* __restrict__ order) {
+    __shared__ int hist[257];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 257; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int s = tid; s < n_seqs; s += 1024) {
+        int L = cu[s + 1] - cu[s];
+        L = L < 1 ? 1 : (L > 256 ? 256 : L);
+        atomicAdd(&hist[256 - L], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {  // exclusive prefix sum: hist[b] becomes the first slot of bin b
+        int run = 0;
+        for (int b = 0; b < 257; ++b) { const int c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int s = tid; s < n_seqs; s += 1024) {
+        int L = cu[s + 1] - cu[s];
+        L = L < 1 ? 1 : (L > 256 ? 256 : L);
+        order[atomicAdd(&hist[256 - L], 1)] = s;
+    }
+}
+
 // ---------------------------------------------------------------- attention, f16x3 arithmetic
 // Same structure as attention_kernel (one block per (sequence, head), S^T on the accumulator rows, P fed
 // back from the accumulators), with both products on the f16 MFMA by the 3-term split of gemm_x3.h:
@@ -1553,7 +1583,8 @@ template <int NKT, int WAVES, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_kernel(const float* __restrict__ qkv,
                                                                   const int32_t* __restrict__ cu, int heads, int H,
                                                                   float scale_log2e, float* __restrict__ ctx,
-                                                                  _Float16* __restrict__ ch, _Float16* __restrict__ cl) {
+                                                                  _Float16* __restrict__ ch, _Float16* __restrict__ cl,
+                                                                  const int32_t* __restrict__ order) {
     // Single-accumulator form of the split (wt_gemm.h): every operand is carried as hi/lo f16 planes of 16 x (Q, K, V)
     // or 1024 p (the probabilities), the three products of a k-step accumulate into ONE fp32 tile, and the power-of-two
     // scales are folded into constants: S' = 256 S, O' = 16384 sum_k p_k V_k, l' = 1024 sum_k p_k, O = O' / (16 l').
@@ -1580,7 +1611,8 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
     _Float16* const Ob = Kbuf;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int sidx = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int s = order != nullptr ? order[sidx] : sidx;  // seq_order_kernel: longest first
     const int t0 = cu[s], L = cu[s + 1] - t0;
     const int nkt = (L + 31) >> 5;
     if (nkt > NKT || (NKT > 1 && nkt <= NKT / 2)) return;  // another bucket's sequence
@@ -1978,7 +2010,8 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
 // costs a few microseconds; single-sequence calls launch exactly one bucket).
 template <bool SPLIT, bool X3>
 static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
-                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st, int buckets = 15) {
+                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st, int buckets = 15,
+                             const int32_t* order = nullptr) {
     // buckets: bit b set = launch the bucket of 2^b key tiles (callers split the buckets over two streams)
     const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
     const int nkt_max = (max_seqlen + 31) / 32;
@@ -1986,7 +2019,7 @@ static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, in
     const dim3 grid1(n_seqs * heads, 1);
 #define ICREC_ATT(NKT, W)                                                                                        \
     do {                                                                                                         \
-        if (X3) hipLaunchKernelGGL((attention_x3_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl); \
+        if (X3) hipLaunchKernelGGL((attention_x3_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl, order); \
         else hipLaunchKernelGGL((attention_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);      \
     } while (0)
     if ((buckets & 1) && (single ? nkt_max == 1 : true)) ICREC_ATT(1, 1);
@@ -2175,6 +2208,17 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     _Float16* hh = reinterpret_cast<_Float16*>(hb);
     _Float16* hl = hh + (size_t)T * I;
 
+    // f16x3 mode: the fp32 x region of the workspace is unused (the residual stream is its two planes): it carries the
+    // attention dispatch order of batches (ICREC_ATT_ORDER=0: workgroup b serves sequence b / heads, A/B)
+    const int32_t* order = nullptr;
+    {
+        const char* ao = getenv("ICREC_ATT_ORDER");
+        if (x3 && n_seqs >= 64 && !(ao && ao[0] == '0')) {
+            int32_t* ord = reinterpret_cast<int32_t*>(x);
+            hipLaunchKernelGGL(seq_order_kernel, dim3(1), dim3(1024), 0, st, cu_dev, n_seqs, ord);
+            order = ord;
+        }
+    }
     if (x3)
         hipLaunchKernelGGL((embed_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T,
                            e->word, e->pos, e->type, e->eg, e->eb, c.ln_eps, c.vocab_size, c.max_position, x, xh, xl);
@@ -2257,12 +2301,12 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 // buckets' workgroups run beside it from the side stream instead of after it
                 ICREC_HIP(hipEventRecord(sd->ev_q, st));
                 ICREC_HIP(hipStreamWaitEvent(sd->side, sd->ev_q, 0));
-                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, sd->side, 7);
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, sd->side, 7, order);
                 ICREC_HIP(hipEventRecord(sd->ev_sa, sd->side));
-                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 8);
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 8, order);
                 ICREC_HIP(hipStreamWaitEvent(st, sd->ev_sa, 0));
             } else {
-                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st);
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 15, order);
             }
             if (T_tail) {
                 if (use_side) {

@@ -196,11 +196,13 @@ def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, 
         other = enc.encode_packed(*args).cpu().numpy()
         monkeypatch.delenv("ICREC_FUSE")
         np.testing.assert_array_equal(fused, other)
-    # the QKV projection: activation-resident kernel (default for batches) vs the slab-ring kernel
-    monkeypatch.setenv("ICREC_QKV_RESIDENT", "0")
-    other = enc.encode_packed(*args).cpu().numpy()
-    monkeypatch.delenv("ICREC_QKV_RESIDENT")
-    np.testing.assert_array_equal(fused, other)
+    # the QKV projection: activation-resident kernel (default for batches) vs the slab-ring kernel;
+    # attention workgroups dispatched longest sequence first (default from 64 sequences) vs in batch order
+    for var in ("ICREC_QKV_RESIDENT", "ICREC_ATT_ORDER"):
+        monkeypatch.setenv(var, "0")
+        other = enc.encode_packed(*args).cpu().numpy()
+        monkeypatch.delenv(var)
+        np.testing.assert_array_equal(fused, other)
     enc.close()
 
 
