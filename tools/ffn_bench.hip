@@ -220,6 +220,10 @@ int main(int argc, char** argv) {
         timeit("qkv wt_linear<3,2,2,0> N=1152", [&] {
             hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         }, 2.0 * T * H * 3 * H);
+        timeit("qkv_resident_kernel N=1152", [&] {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QKVR_LDS);
+            hipLaunchKernelGGL(qkv_resident_kernel, dim3((T + 63) / 64), dim3(512), QKVR_LDS, 0, xh, xl, T, Wqp, bq, qkv, 3 * H);
+        }, 2.0 * T * H * 3 * H);
         timeit("attn-out + LN wt_linear_ln<2>", [&] {
             hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, xh, xl, g, bn, 1e-12f);
         }, 2.0 * T * H * H);
