@@ -37,8 +37,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)  # >= 200 timed iterations after 20 warm-ups
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None,
                     help="user contexts per GPU per step (default: 1024 on one GPU = BASELINE configs[1]/[2]; "
                          "4096 / N at N > 1 = configs[3]'s 4,096-query batch over the sharded catalog)")
