@@ -1860,6 +1860,12 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
         }
     }
     ICREC_STAMP(0, 5);
+#ifdef ICREC_STAMPS
+    if (threadIdx.x == 0) {  // where this workgroup ran: HW_ID (cu / sh / se in bits 8..15) and XCC_ID, for the per-CU timeline of the harness
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        g_stamps[((size_t)blockIdx.x * 2) * 64 + 8] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- mean pooling + L2 normalise

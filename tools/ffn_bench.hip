@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
 #include <vector>
 
 using namespace icrec;
@@ -180,6 +181,32 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr);
             hipDeviceSynchronize();
             dump("attention long (L=200) wave0", nseq * 12, 0, {0, 1, 2, 3, 4, 5});
+            {   // per-CU timeline: how much of a CU's span is covered by 0 / 1 / 2 resident workgroups
+                const int nblk = nseq * 12;
+                std::vector<unsigned long long> hs((size_t)nblk * 128);
+                hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_stamps), hs.size() * 8);
+                std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> ev;
+                for (int bI = 0; bI < nblk; ++bI) {
+                    const unsigned long long id = hs[(size_t)bI * 128 + 8], cu = ((id >> 32) << 16) | (id & 0xFF00);
+                    ev[cu].push_back({hs[(size_t)bI * 128 + 0], +1});
+                    ev[cu].push_back({hs[(size_t)bI * 128 + 5], -1});
+                }
+                double cov[4] = {0, 0, 0, 0}, span = 0, life = 0;
+                for (auto& kv : ev) {
+                    auto& v = kv.second;
+                    std::sort(v.begin(), v.end());
+                    int c = 0;
+                    for (size_t i = 0; i + 1 < v.size(); ++i) {
+                        c += v[i].second;
+                        cov[c > 3 ? 3 : c] += (double)(v[i + 1].first - v[i].first);
+                    }
+                    span += (double)(v.back().first - v.front().first);
+                }
+                for (int bI = 0; bI < nblk; ++bI) life += (double)(hs[(size_t)bI * 128 + 5] - hs[(size_t)bI * 128 + 0]);
+                printf("attention per-CU timeline: %zu CUs, mean span %.0f ticks, resident workgroups 0: %.1f%%  1: %.1f%%  2: %.1f%%  3+: %.1f%%, "
+                       "workgroups per CU %.1f, mean life %.0f ticks\n", ev.size(), span / ev.size(), 100 * cov[0] / span, 100 * cov[1] / span,
+                       100 * cov[2] / span, 100 * cov[3] / span, (double)nblk / ev.size(), life / nblk);
+            }
             timeit("attention_x3<8,8> 512 seq x 200 tok", [&] {
                 hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr);
             }, 4.0 * nseq * 12 * Ls * Ls * 32);
