@@ -73,6 +73,11 @@ def lib() -> C.CDLL:
         raise IcrecError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: it brings its own libamdhip64 / librccl, and libicrec must resolve to THAT runtime - loaded before
+    # torch it binds /opt/rocm's copy instead, the process then holds two HIP runtimes and the second one sees no
+    # device ("no ROCm-capable device is detected" from hipSetDevice inside icrec_encoder_create)
+    import torch  # noqa: F401
+
     L = C.CDLL(str(LIB_PATH))
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     sig = {
