@@ -95,3 +95,20 @@ def test_comm_entry_points_validate_arguments(native):
     assert lib.icrec_comm_world(None) == 0 and lib.icrec_comm_rank(None) == -1
     assert lib.icrec_search_sharded_workspace_bytes(None, None, 4, 20) == 0
     assert lib.icrec_index_dim(None) == 0 and lib.icrec_index_device(None) == -1
+
+
+def test_lib_shares_torchs_hip_runtime():
+    """libicrec.so must bind the HIP runtime torch ships (one runtime per process): _native.lib() imports torch before
+    it maps the library, so that a process which builds / loads the library first and touches torch later (the
+    driver's build() then smoke() in one interpreter) does not end up with /opt/rocm's runtime beside torch's — the
+    second one then reports "no ROCm-capable device is detected"."""
+    import subprocess
+    import sys
+
+    code = ("import sys; from instacart_next_order_recommendation_amd import _native; "
+            "assert 'torch' not in sys.modules; _native.lib(); assert 'torch' in sys.modules; "
+            "maps = open('/proc/self/maps').read(); "
+            "hip = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}); "
+            "assert len(hip) == 1 and '/torch/lib/' in hip[0], hip; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(ROOT))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
