@@ -31,7 +31,7 @@ from prometheus_client import CONTENT_TYPE_LATEST, generate_latest
 
 from ..recommender import MonitoredRecommender, Recommender
 from ..recommender import MonitoredRecommender as _MonitoredType  # isinstance target (tests patch the constructor name)
-from .batcher import MicroBatcher
+from .batcher import BatcherStopped, MicroBatcher
 from .metrics import (API_REGISTRY, MODEL_LOADED, RECOMMENDATION_BATCH_SIZE, RECOMMENDATION_ENCODE_SECONDS,
                       RECOMMENDATION_LATENCY_SECONDS, RECOMMENDATION_REQUESTS_TOTAL)
 from .schemas import (CorpusUploadRequest, CorpusUploadResponse, HealthResponse, InferenceStatistics,
@@ -77,6 +77,7 @@ async def lifespan(app: FastAPI) -> AsyncIterator[None]:
     sock_path = os.getenv("ICREC_GPU_WORKER_SOCKET")
     if sock_path:
         _install_frontend(app, sock_path, corpus_path)
+        await app.state.batcher.start()  # connect now: /ready reflects the worker socket from the first probe on
     else:
         logger.info("Loading recommender model_dir=%s corpus=%s", model_dir, corpus_path)
         _install(app, MonitoredRecommender(model_dir=model_dir, corpus_path=corpus_path), corpus_path)
@@ -182,6 +183,9 @@ async def health() -> HealthResponse:
 @app.get("/ready", response_model=HealthResponse)
 async def ready(request: Request) -> HealthResponse:
     ok = bool(getattr(request.app.state, "ready", False)) and getattr(request.app.state, "recommender", None)
+    # front-end of the multi-process server: ready only while the socket to the GPU-owner process is up
+    if ok and getattr(getattr(request.app.state, "batcher", None), "connected", True) is False:
+        ok = False
     return HealthResponse(status="ready" if ok else "not_ready")
 
 
@@ -216,7 +220,15 @@ async def recommend_endpoint(payload: RecommendationRequest, request: Request,
         batcher: Optional[MicroBatcher] = getattr(request.app.state, "batcher", None)
         if batcher is not None and hasattr(recommender, "recommend_batch") and not _is_mock(recommender):
             t_submit = time.time()
-            results, tm = await batcher.submit(retrieval_query, payload.top_k, exclude_ids)
+            try:
+                results, tm = await batcher.submit(retrieval_query, payload.top_k, exclude_ids, user_id_str)
+            except BatcherStopped:  # raced an /admin/corpus swap: the app holds the new pair by now
+                batcher, recommender = request.app.state.batcher, request.app.state.recommender
+                results, tm = await batcher.submit(retrieval_query, payload.top_k, exclude_ids, user_id_str)
+            except Exception as exc:  # noqa: BLE001
+                if type(exc).__name__ == "WorkerUnavailable":  # front-end mode: the GPU-owner process is gone
+                    raise HTTPException(status_code=status.HTTP_503_SERVICE_UNAVAILABLE, detail=str(exc)) from exc
+                raise
             RECOMMENDATION_BATCH_SIZE.observe(tm.batch_size)
             if isinstance(recommender, _MonitoredType) or getattr(recommender, "reports_stats", False) is True:
                 n = len(results)

@@ -31,11 +31,16 @@ class CorpusView:
         raise RuntimeError("front-end processes forward to the GPU worker")
 
 
+class WorkerUnavailable(RuntimeError):
+    """The GPU-owner process cannot be reached (the route answers 503)."""
+
+
 class RemoteBatcher:
     """MicroBatcher's `submit` interface over the worker socket."""
 
-    def __init__(self, sock_path: str, on_corpus=None):
+    def __init__(self, sock_path: str, on_corpus=None, call_timeout: float = 30.0):
         self.sock_path = sock_path
+        self.call_timeout = float(call_timeout)
         self._reader: Optional[asyncio.StreamReader] = None
         self._writer: Optional[asyncio.StreamWriter] = None
         self._pending: dict[int, asyncio.Future] = {}
@@ -51,17 +56,19 @@ class RemoteBatcher:
                 self._task = asyncio.create_task(self._read_loop())
 
     async def stop(self) -> None:
-        if self._task is not None:
-            self._task.cancel()
-            self._task = None
-        if self._writer is not None:
-            self._writer.close()
-            self._writer = None
+        task, self._task = self._task, None
+        if task is not None:
+            task.cancel()  # the read loop's `finally` closes the transport and fails what is in flight
+
+    @property
+    def connected(self) -> bool:
+        return self._writer is not None and not self._writer.is_closing()
 
     async def _read_loop(self) -> None:
+        reader = self._reader
         try:
             while True:
-                msg = await read_frame(self._reader)
+                msg = await read_frame(reader)
                 kind, rid = msg[0], msg[1]
                 if kind == "corpus" and self._on_corpus is not None:
                     self._on_corpus(msg[2])
@@ -74,23 +81,45 @@ class RemoteBatcher:
                     fut.set_result((msg[2], int(msg[3])))
                 else:
                     fut.set_exception(RuntimeError(msg[2]))
-        except (asyncio.IncompleteReadError, ConnectionResetError, asyncio.CancelledError):
+        except (asyncio.IncompleteReadError, ConnectionError, OSError, asyncio.CancelledError):
+            pass
+        finally:
+            # the connection is gone (worker died / socket reset / stop()): fail everything in flight and forget the
+            # transport, so that later calls reconnect or fail at once instead of writing into a dead socket
+            w, self._writer, self._reader = self._writer, None, None
+            if w is not None:
+                w.close()
             for fut in self._pending.values():
                 if not fut.done():
-                    fut.set_exception(RuntimeError("GPU worker connection lost"))
+                    fut.set_exception(WorkerUnavailable("GPU worker connection lost"))
             self._pending.clear()
 
     async def _call(self, msg_tail, kind: str):
         if self._writer is None:
-            await self.start()
+            try:
+                await self.start()  # first use, or the previous connection was lost: (re)connect
+            except OSError as exc:
+                raise WorkerUnavailable(f"GPU worker unreachable: {exc}") from exc
+        writer = self._writer
+        if writer is None or writer.is_closing():
+            raise WorkerUnavailable("GPU worker connection lost")
         rid = next(self._ids)
         fut = asyncio.get_running_loop().create_future()
         self._pending[rid] = fut
-        self._writer.write(frame([kind, rid, *msg_tail]))
-        return await fut
+        try:
+            writer.write(frame([kind, rid, *msg_tail]))
+        except Exception as exc:  # noqa: BLE001 - a transport error must not leave the future registered
+            self._pending.pop(rid, None)
+            raise WorkerUnavailable(f"GPU worker connection lost: {exc}") from exc
+        timeout = self.call_timeout if kind == "rec" else None  # a re-index legitimately takes long
+        try:
+            return await asyncio.wait_for(fut, timeout)
+        except asyncio.TimeoutError:
+            self._pending.pop(rid, None)
+            raise WorkerUnavailable(f"GPU worker did not answer within {timeout:.0f}s") from None
 
-    async def submit(self, query: str, top_k: int, exclude):
-        return await self._call([query, int(top_k), sorted(exclude) if exclude else []], "rec")
+    async def submit(self, query: str, top_k: int, exclude, user_id: Optional[str] = None):
+        return await self._call([query, int(top_k), sorted(exclude) if exclude else [], user_id], "rec")
 
     async def reindex(self, corpus_path: str):
         """-> (corpus_path, n_products) once the worker has swapped in the new catalog."""

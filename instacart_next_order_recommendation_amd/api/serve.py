@@ -63,12 +63,32 @@ def main() -> None:
     procs, _ = start(args.workers, args.host, args.port, model_dir, corpus_path)
     print(f"serving on {args.host}:{args.port} with {args.workers} front-ends + 1 GPU worker", flush=True)
     signal.signal(signal.SIGTERM, lambda *_: (_ for _ in ()).throw(KeyboardInterrupt()))
+    raise SystemExit(supervise(procs))
+
+
+def supervise(procs, poll_s: float = 0.5) -> int:
+    """Block until any child exits (or SIGTERM / Ctrl-C), then stop every other one.  A dead GPU worker must not
+    leave N front-ends accepting requests they cannot serve: the whole server exits non-zero and whoever runs it
+    (systemd, k8s) starts a fresh set of processes - a process that touched the GPU is never re-exec'd."""
+    import time
+
+    code = 0
     try:
-        for p in procs:
-            p.join()
+        while True:
+            dead = [p for p in procs if not p.is_alive()]
+            if dead:
+                code = next((p.exitcode for p in dead if p.exitcode), 0) or 1
+                print(f"child process {dead[0].name} exited ({dead[0].exitcode}); stopping the server", flush=True)
+                break
+            time.sleep(poll_s)
     except KeyboardInterrupt:
-        for p in procs:
+        pass
+    for p in procs:
+        if p.is_alive():
             p.terminate()
+    for p in procs:
+        p.join(10)
+    return code
 
 
 if __name__ == "__main__":

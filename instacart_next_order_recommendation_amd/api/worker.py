@@ -4,7 +4,7 @@ One process holds the MonitoredRecommender (model + catalog index in HBM) and ru
 front-end processes (FastAPI app, one event loop each) parse / validate / serialise HTTP and forward
 (query, top_k, exclusions) over a Unix socket.  Frames: 4-byte little-endian length + msgpack.
 
-    front-end -> worker   ["rec", rid, query, top_k, [excluded product ids]]
+    front-end -> worker   ["rec", rid, query, top_k, [excluded product ids], user_id | None]
                           ["corpus", rid, corpus_path]              (POST /admin/corpus: re-index)
     worker -> front-end   ["ok", rid, [[pid, score], ...], encode_ms, search_ms, batch_size]
                           ["err", rid, message]
@@ -23,6 +23,8 @@ import struct
 from pathlib import Path
 
 import msgpack
+
+from .batcher import BatcherStopped
 
 logger = logging.getLogger(__name__)
 
@@ -62,11 +64,19 @@ class GpuWorker:
         kind, rid = msg[0], msg[1]
         try:
             if kind == "rec":
-                results, tm = await self.batcher.submit(msg[2], int(msg[3]), set(msg[4]) if msg[4] else None)
+                for attempt in (0, 1):
+                    try:
+                        results, tm = await self.batcher.submit(msg[2], int(msg[3]), set(msg[4]) if msg[4] else None,
+                                                                msg[5] if len(msg) > 5 else None)
+                        break
+                    except BatcherStopped:  # raced a corpus swap: self.batcher is the new one by now
+                        if attempt:
+                            raise
                 writer.write(frame(["ok", rid, results, tm.encode_ms, tm.search_ms, tm.batch_size]))
             elif kind == "corpus":
                 # build the NEW recommender off the event loop (a full GPU re-encode), keep serving the old one
-                # meanwhile, then swap batcher + recommender in one step and tell every front-end
+                # meanwhile, then swap batcher + recommender in one step and tell every front-end; the old batcher
+                # stops gracefully: what it has queued (and the batch on the GPU) is still answered
                 new_rec = await asyncio.get_running_loop().run_in_executor(None, self._mk, Path(msg[2]))
                 old = self.batcher
                 self.recommender, self.batcher, self.corpus_path = new_rec, self._new_batcher(new_rec), Path(msg[2])

@@ -70,7 +70,6 @@ class DeviceEncoder:
         self._h = h
         self._ws_slots: dict[int, Optional[torch.Tensor]] = {}
         self._side: Optional[torch.cuda.Stream] = None
-        self._split_cu = None
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -119,10 +118,10 @@ class DeviceEncoder:
             return out
         half = n // 2
         t_half = int(cu_host[half])
-        key = (cu.data_ptr(), half, t_half)
-        if self._split_cu is None or self._split_cu[0] != key:   # second half's rebased cu_seqlens (cached)
-            self._split_cu = (key, (cu[half:] - t_half).contiguous())
-        cu_b = self._split_cu[1]
+        # the second half's rebased cu_seqlens, computed per call on the caller's stream (one tiny kernel).  Never
+        # cached by address: the allocator hands the next batch's cu tensor the same address, and two different
+        # batches with equal n and t_half would then share stale sequence boundaries.
+        cu_b = cu[half:] - t_half
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)

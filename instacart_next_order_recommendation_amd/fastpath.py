@@ -50,7 +50,7 @@ class _Captured:
         self.srch_ws = torch.empty(int(L.icrec_search_workspace_bytes(index._h, 1, k)), dtype=torch.uint8, device=dev)
         P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
-        def body():
+        def body_encode():
             self.ids.copy_(self.d_in[:bucket])
             self.cu.copy_(self.d_in[bucket:bucket + 2])
             self.excl_off.copy_(self.d_in[bucket + 2:bucket + 4])
@@ -58,20 +58,42 @@ class _Captured:
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _native.check(L.icrec_encode(enc._h, P(self.ids), P(self.cu), 1, bucket, bucket, P(self.emb),
                                          P(self.enc_ws), self.enc_ws.numel(), st), "icrec_encode")
+
+        def body_search():
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _native.check(L.icrec_search(index._h, P(self.emb), 1, k, P(self.excl_idx), P(self.excl_off),
                                          P(self.out_idx), P(self.out_sc), P(self.srch_ws), self.srch_ws.numel(), st),
                           "icrec_search")
 
+        self._bodies = (body_encode, body_search)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up: function attributes, workspaces
-            body()
-            body()
+            for _ in range(2):
+                body_encode()
+                body_search()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            body()
+            body_encode()
+            body_search()
+        self.timed: Optional[tuple] = None
+
+    def timed_graphs(self):
+        """(encode graph, search graph, three timing events): the same request as `graph` cut at the encode /
+        search seam, so that MonitoredRecommender's query_embedding_time_ms / similarity_compute_time_ms come
+        from HIP events around the two replays (same buffers, same kernels; captured on first use)."""
+        if self.timed is None:
+            torch.cuda.synchronize(self.ids.device)
+            graphs = []
+            for body in self._bodies:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                graphs.append(g)
+            self.timed = (graphs[0], graphs[1], tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)))
+        return self.timed
 
 
 class SingleRequestPath:
@@ -93,8 +115,10 @@ class SingleRequestPath:
     def supports(self, n_tokens: int, k: int, n_excluded: int) -> bool:
         return 1 <= n_tokens <= BUCKETS[-1] and n_excluded <= MAX_EXCLUDED and k <= self.index.n_rows
 
-    def run(self, ids: Sequence[int], k: int, excluded_rows: Optional[Sequence[int]] = None):
-        """-> (row indices int64 [k], scores float32 [k]) on the host; -1 / 0 padded like icrec_search."""
+    def run(self, ids: Sequence[int], k: int, excluded_rows: Optional[Sequence[int]] = None, timed: bool = False):
+        """-> (row indices int64 [k], scores float32 [k]) on the host; -1 / 0 padded like icrec_search.
+        timed=True: the request runs as two replays (encode, search) bracketed by HIP events and the call
+        returns (idx, scores, encode_ms, search_ms)."""
         n = len(ids)
         ex = sorted(set(int(r) for r in excluded_rows)) if excluded_rows else []
         if not self.supports(n, k, len(ex)):
@@ -117,9 +141,20 @@ class SingleRequestPath:
         if ex:
             h[bucket + 4:bucket + 4 + len(ex)] = torch.as_tensor(ex, dtype=torch.int32)
         stream = torch.cuda.current_stream(self.encoder.device)
+        if timed:
+            g_enc, g_srch, (e0, e1, e2) = c.timed_graphs()
         c.d_in.copy_(h, non_blocking=True)
-        c.graph.replay()
+        if timed:
+            e0.record(stream)
+            g_enc.replay()
+            e1.record(stream)
+            g_srch.replay()
+            e2.record(stream)
+        else:
+            c.graph.replay()
         c.h_idx.copy_(c.out_idx, non_blocking=True)
         c.h_sc.copy_(c.out_sc, non_blocking=True)
         stream.synchronize()
+        if timed:
+            return c.h_idx[0].numpy().copy(), c.h_sc[0].numpy().copy(), e0.elapsed_time(e1), e1.elapsed_time(e2)
         return c.h_idx[0].numpy().copy(), c.h_sc[0].numpy().copy()

@@ -297,18 +297,23 @@ class Recommender:
                   exclude_product_ids: set[str] | None = None) -> list[tuple[str, float]]:
         """Top-k (product_id, score) by cosine similarity, best first (reference :206-225).
         One query = one hipGraph replay (fastpath.py) when ICREC_USE_GRAPH is not "0"."""
-        if self._fast is not None:
-            if self._fast.index is not self._index or self._fast.encoder is not self.model.encoder:
-                # a captured graph bakes the index / encoder handles: a rebuilt index or model drops every graph
-                self._fast = type(self._fast)(self.model.encoder, self._index)
+        fast = self._fast_path()
+        if fast is not None:
             top_k = max(int(top_k), 1)
             ids = self.model.tokenizer([query])[0]
             ex = self._excluded_rows(exclude_product_ids)
             k = min(top_k, len(self.product_ids))
-            if top_k <= _native.ICREC_MAX_K and self._fast.supports(len(ids), k, len(ex)):
-                idx, sc = self._fast.run(ids, k, ex)
+            if top_k <= _native.ICREC_MAX_K and fast.supports(len(ids), k, len(ex)):
+                idx, sc = fast.run(ids, k, ex)
                 return self._to_results(idx, sc)
         return self.recommend_batch([query], top_k, [exclude_product_ids])[0]
+
+    def _fast_path(self):
+        """The hipGraph single-request path, rebuilt when the index or the model was replaced under it (a captured
+        graph bakes the index / encoder handles), or None under ICREC_USE_GRAPH=0."""
+        if self._fast is not None and (self._fast.index is not self._index or self._fast.encoder is not self.model.encoder):
+            self._fast = type(self._fast)(self.model.encoder, self._index)
+        return self._fast
 
 
 class MonitoredRecommender(Recommender):
@@ -325,10 +330,21 @@ class MonitoredRecommender(Recommender):
                   exclude_product_ids: set[str] | None = None) -> list[tuple[str, float]]:
         start = time.time()
         top_k = max(int(top_k), 1)  # the reference's loop appends before testing len >= top_k (:259-262)
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t_tok = time.time()
         ids = self.model.tokenizer([query])
         tok_ms = (time.time() - t_tok) * 1000
+        fast = self._fast_path()
+        if fast is not None and top_k <= _native.ICREC_MAX_K:
+            # the same replayed request as Recommender.recommend, cut at the encode / search seam with HIP events
+            # around the two replays (fastpath.py): the three timing fields keep their meaning on the graph path
+            ex_rows = self._excluded_rows(exclude_product_ids)
+            k = min(top_k, len(self.product_ids))
+            if fast.supports(len(ids[0]), k, len(ex_rows)):
+                idx1, sc1, enc_ms, sim_ms = fast.run(ids[0], k, ex_rows, timed=True)
+                results = self._to_results(idx1, sc1)
+                self.note_served(results, user_id, tok_ms + enc_ms, sim_ms, (time.time() - start) * 1000)
+                return results
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         stream = torch.cuda.current_stream(self.device)
         e0.record(stream)
         emb = self.model.encoder.encode_ids(ids)
@@ -343,15 +359,22 @@ class MonitoredRecommender(Recommender):
         encode_ms = tok_ms + e0.elapsed_time(e1)
         sim_ms = e1.elapsed_time(e2)
         results = self._to_results(idx[0], sc[0])
-        total_ms = (time.time() - start) * 1000
-        top_score = results[0][1] if results else 0.0
-        avg_score = sum(s for _, s in results) / len(results) if results else 0.0
-        self.last_metrics = RecommendationMetrics(
-            user_id=user_id or "anonymous", query_embedding_time_ms=encode_ms, similarity_compute_time_ms=sim_ms,
-            total_latency_ms=total_ms, num_recommendations=len(results), top_score=top_score, avg_score=avg_score,
-            timestamp=time.time())
-        self._log_metrics(self.last_metrics)
+        self.note_served(results, user_id, encode_ms, sim_ms, (time.time() - start) * 1000)
         return results
+
+    def note_served(self, results: list[tuple[str, float]], user_id: Optional[str], encode_ms: float, sim_ms: float,
+                    total_ms: float) -> RecommendationMetrics:
+        """Fill last_metrics and emit the `recommendation_served` record for ONE served request (reference
+        :268-278).  recommend() calls it per request; the micro-batching server calls it once per request of a
+        batch with the batch's timings (api/batcher.py)."""
+        n = len(results)
+        m = self.last_metrics = RecommendationMetrics(
+            user_id=user_id or "anonymous", query_embedding_time_ms=encode_ms, similarity_compute_time_ms=sim_ms,
+            total_latency_ms=total_ms, num_recommendations=n, top_score=results[0][1] if results else 0.0,
+            avg_score=sum(s for _, s in results) / n if n else 0.0, timestamp=time.time())
+        if self.metrics_logger.isEnabledFor(logging.INFO):
+            self._log_metrics(m)
+        return m
 
     def _log_metrics(self, m: RecommendationMetrics) -> None:
         self.metrics_logger.info("recommendation_served", extra={
