@@ -107,13 +107,15 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
 
 
 def load_traffic(kernel_key: str):
-    """HBM-side bytes per launch of `kernel_key` from the committed PMC record (profiles/r02_roofline_traffic.json:
-    two rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 rule, WRITE_SIZE as is; written by
-    tools/pmc_traffic_json.py).  (None, note) when the record is missing."""
-    path = ROOT / "profiles" / "r02_roofline_traffic.json"
+    """HBM-side bytes per launch of `kernel_key` as RECORDED by the last committed PMC run (profiles/
+    r0N_roofline_traffic.json: two rocprofv3 --pmc passes over this bench command, FETCH_SIZE doubled per the gfx950
+    rule, WRITE_SIZE as is; written by tools/pmc_traffic_json.py) - counters cannot be read from inside the timed
+    process, so this field is a recorded value, not one measured by this run.  (None, note) when the record is missing."""
+    paths = sorted((ROOT / "profiles").glob("r0*_roofline_traffic.json"))
+    path = paths[-1] if paths else ROOT / "profiles" / "roofline_traffic.json"
     try:
         rec = json.loads(path.read_text())[kernel_key]
-        return float(rec["traffic_bytes"]), f"{rec['note']} ({path.name})"
+        return float(rec["traffic_bytes"]), f"RECORDED, not measured by this run: {rec['note']} ({path.name})"
     except Exception:  # noqa: BLE001
         return None, f"no PMC record for {kernel_key} in {path.name}"
 
@@ -211,15 +213,21 @@ def main() -> None:
     # torch.distributed only carries the 128-byte rendezvous id, the barrier and the max-over-ranks of the clock
     comm, comm_note = None, None
     if world > 1 and not rehearsal:
+        # from_process_group keeps every rank on ONE collective sequence: each rank loads librccl (a local step),
+        # rank 0's id travels behind a status byte, an all_reduce(MIN) of "loaded and have the id" decides for all
+        # ranks before anyone enters ncclCommInitRank - a rank that cannot start never leaves the others waiting in
+        # a collective it does not join.  (A rank that dies INSIDE ncclCommInitRank stalls the others there: RCCL's
+        # semantics, not recoverable here.)
         try:
             comm = NativeComm.from_process_group(dev)
-        except Exception as exc:  # noqa: BLE001 - keep the scaling run alive: same kernels, collectives through torch.distributed
-            comm_note = f"icrec_comm_init failed ({type(exc).__name__}: {exc}); exchange through torch.distributed (RCCL) instead"
+        except Exception as exc:  # noqa: BLE001 - raised on EVERY rank alike: the same kernels, collectives through torch.distributed
+            comm_note = f"icrec_comm_init not usable ({type(exc).__name__}: {exc}); exchange through torch.distributed (RCCL) instead"
         ok = torch.tensor([1 if comm is not None else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must take the same path
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # ncclCommInitRank itself failed on some rank: all fall back together
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
             comm = None
+            comm_note = "ncclCommInitRank failed on another rank; exchange through torch.distributed (RCCL) instead"
     search = ShardedSearch(backend, lo, hi, comm=comm)
 
     # ---- this rank's batch of user contexts as packed token ids, resident in HBM
@@ -258,6 +266,29 @@ def main() -> None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- N > 1: the exchange validates itself.  Every rank searches a 64-query sample of the gathered batch against
+    # a replicated, UNSHARDED copy of the catalog and compares with what the sharded step just returned for those
+    # queries: a rank-major layout slip in either all-gather would still produce a plausible QPS, not equal bits.
+    exchange_verified = None
+    if world > 1 and args.workload == "49k7":
+        from instacart_next_order_recommendation_amd.search import DeviceIndex
+
+        q_all = search.gather_queries(emb)  # torch.distributed all-gather: independent of the library's own
+        n_all = int(q_all.shape[0])
+        sample = torch.linspace(0, n_all - 1, steps=min(64, n_all), device=dev).round().long().unique()
+        full = DeviceIndex(torch.from_numpy(catalog).to(dev), dev, storage="f32")
+        ref_idx, ref_sc = full.search(q_all[sample], TOP_K)
+        same = bool(torch.equal(ref_idx, idx[sample]) and torch.equal(ref_sc, sc[sample])) and idx.shape[0] == n_all
+        flag = torch.tensor([1 if same else 0], device=dev)
+        if dist.get_backend() == "gloo":
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange_verified = bool(int(flag.item()) == 1)
+        full.close()
+        if not exchange_verified:
+            raise SystemExit(f"rank {rank}: sharded result differs from the unsharded search on the 64-query sample "
+                             f"(this rank: {'equal' if same else 'DIFFERENT'})")
 
     # ---- the same step with the product's two-stream encode (DeviceEncoder splits the batch over two HIP
     # streams when it has the host copy of cu_seqlens, as recommend_batch does).  Reported separately: the
@@ -298,9 +329,32 @@ def main() -> None:
         torch.cuda.synchronize(dev)
         dt32 = (time.perf_counter() - t32) / 5
         step()
+        # queries whose ordered top-20 differs between the two modes: are they near-ties?  The two embeddings differ by
+        # ~2e-7, so two catalog rows can swap only when their scores are closer than that; SURVEY 7.2.1 calls a list
+        # AMBIGUOUS when the exact-mode scores of its top-21 hold a gap below 4e-6.  `unexplained` must be 0.
+        differ = (~(i32 == idx).all(dim=1)).nonzero().flatten()
+        n_amb = n_unexpl = 0
+        if differ.numel():
+            _, s21 = search.search(emb32[differ], TOP_K + 1)
+            gaps = (s21[:, :-1] - s21[:, 1:]).min(dim=1).values
+            n_amb = int((gaps < 4e-6).sum().item())
+            n_unexpl = int(differ.numel()) - n_amb
+            # and the stronger statement: the two lists hold the same rows up to swaps across such near-ties
+            worst_swap = 0.0
+            s32c, i32c, idc = s32[differ].cpu().numpy(), i32[differ].cpu().numpy(), idx[differ].cpu().numpy()
+            for r in range(len(idc)):
+                for pos in np.nonzero(i32c[r] != idc[r])[0]:
+                    j = np.nonzero(i32c[r] == idc[r][pos])[0]
+                    worst_swap = max(worst_swap, abs(float(s32c[r][pos] - s32c[r][j[0]])) if len(j) else
+                                     abs(float(s32c[r][pos] - s32c[r][-1])))
         f32_leg = {"qps": args.batch / dt32, "ms_per_step": dt32 * 1e3,
                    "max_abs_embedding_diff_vs_default_mode": float((emb32 - emb).abs().max().item()),
                    "top20_lists_identical_to_default_mode": float((i32 == idx).all(dim=1).float().mean().item()),
+                   "top20_lists_that_differ": {
+                       "count": int(differ.numel()), "ambiguous_top21_gap_below_4e-6": n_amb, "unexplained": n_unexpl,
+                       "largest_exact_mode_score_gap_across_a_swapped_pair": worst_swap if differ.numel() else 0.0,
+                       "note": "exact-mode (f32) scores of the differing queries' top-21: a list counts as ambiguous when its "
+                               "smallest adjacent gap is < 4e-6 (SURVEY 7.2.1); rows that changed place are that close in score"},
                    "note": "gemm_mode=f32: exact-f32 MFMA everywhere (157 TF roof); same inputs, same search"}
         del enc32, emb32
 
@@ -361,7 +415,7 @@ def main() -> None:
 
     # ---- the same step from TEXT in host memory (not `value`): native tokenizer on the host cores, one
     # H2D of the packed ids, encode + search, D2H of the results — the PCIe- and tokeniser-inclusive rate
-    text_path = None
+    text_path = strings_pipelined = None
     if rank == 0 and world == 1 and args.workload == "49k7" and not args.no_latency:
         import tempfile
 
@@ -390,27 +444,75 @@ def main() -> None:
             tok_s += dt
         wall = time.perf_counter() - t_a
         # the same steps through the product's two-deep pipeline (pipeline.py, Recommender.recommend_batches):
-        # batch i+1 is tokenised on a worker thread while the GPU works on batch i
+        # batch i+1 is tokenised on a worker thread while the GPU works on batch i.  Timed over --steps batches
+        # (warm-up first), cycling through FOUR different batches of contexts so that no call sees the previous
+        # call's strings, ids or sequence boundaries again.
         from instacart_next_order_recommendation_amd.pipeline import pipelined_search
 
-        n_pipe = 8
-        list(pipelined_search(tok, enc, lambda e, k, ex: search.search(e, k), [texts] * 2, TOP_K))
+        text_batches = [texts] + [syn.synthetic_user_contexts(args.batch, seed=4321 + b, max_items=36, min_orders=3,
+                                                               max_orders=8, per_order=8) for b in range(3)]
+        n_pipe = max(args.steps, 8)
+        srch = lambda e, k, ex: search.search(e, k)  # noqa: E731
+        list(pipelined_search(tok, enc, srch, [text_batches[i % 4] for i in range(max(args.warmup, 2))], TOP_K))
         t_p = time.perf_counter()
-        n_out = sum(r[0].shape[0] for r in pipelined_search(tok, enc, lambda e, k, ex: search.search(e, k),
-                                                            [texts] * n_pipe, TOP_K))
+        n_out = sum(r[0].shape[0] for r in pipelined_search(tok, enc, srch, (text_batches[i % 4] for i in range(n_pipe)), TOP_K))
         wall_p = time.perf_counter() - t_p
         assert n_out == args.batch * n_pipe
+        pipe_tokens = [int(tok.packed(b)[1][-1]) for b in text_batches]
         text_path = {"qps": args.batch * reps / wall, "ms_per_step": wall / reps * 1e3,
-                     "pipelined": {"qps": n_out / wall_p, "ms_per_step": wall_p / n_pipe * 1e3, "batches": n_pipe,
-                                   "note": "Recommender.recommend_batches / pipeline.py: tokenisation of batch i+1 on a "
-                                           "worker thread under the GPU work of batch i, results read back from pinned "
-                                           "buffers after the next launch"},
                      "tokenize_ms_per_step": tok_s / reps * 1e3, "tokens_per_step": n_tok_text,
                      "host_threads": "min(CPU quota, texts/64) worker threads inside icrec_tokenize", "host_cpus_visible": os.cpu_count(),
                      "mean_tokens_per_context": n_tok_text / args.batch,
                      "note": "synthetic user-context STRINGS (~128 tokens each, like the token-id batches `value` is "
                              "measured on) -> native WordPiece on the host -> H2D -> encode -> "
-                             "search -> D2H, strictly serial (no overlap of tokenisation with GPU work)"}
+                             "search -> D2H, strictly serial (no overlap of tokenisation with GPU work); 5 steps"}
+        strings_pipelined = {"qps": n_out / wall_p, "ms_per_step": wall_p / n_pipe * 1e3, "steps": n_pipe,
+                             "warmup": max(args.warmup, 2), "distinct_batches": 4,
+                             "mean_tokens_per_context": float(np.mean(pipe_tokens)) / args.batch,
+                             "fraction_of_ids_resident_value": (n_out / wall_p) / (args.batch * args.steps / elapsed),
+                             "note": "north_star's workload: synthetic user-context STRINGS in host memory -> top-20 rows "
+                                     "and scores in host memory, through Recommender.recommend_batches' pipeline "
+                                     "(pipeline.py): native WordPiece of batch i+1 on a worker thread under the GPU work "
+                                     "of batch i, results read back from pinned buffers after the next launch"}
+
+    # ---- single request from a STRING through the serving objects themselves (what /recommend constructs:
+    # MonitoredRecommender, reference src/api/main.py:73): tokenise -> replayed hipGraph(s) -> k results on the host
+    p50_rec_ms = p50_mon_ms = mon_fields = None
+    if rank == 0 and world == 1 and args.workload == "49k7" and not args.no_latency:
+        import tempfile
+
+        from instacart_next_order_recommendation_amd.model_io import write_synthetic_model_dir
+        from instacart_next_order_recommendation_amd.recommender import MonitoredRecommender
+
+        root = Path(tempfile.mkdtemp(prefix="icrec_bench_rec_"))
+        mdir = write_synthetic_model_dir(root / "model", seed=0)
+        (root / "processed").mkdir()
+        cpath = root / "processed" / "eval_corpus.json"
+        cpath.write_text(json.dumps(syn.synthetic_catalog(CATALOG_ROWS)))
+        logging_off = __import__("logging").getLogger("recommender.metrics")
+        logging_off.setLevel(__import__("logging").WARNING)
+        mon = MonitoredRecommender(mdir, cpath, use_index=False)
+        one_text = syn.synthetic_user_contexts(4, seed=77, max_items=28, min_orders=3, max_orders=6, per_order=7)[1]
+
+        def p50_of(fn, n=110):
+            lat = []
+            for _ in range(n):
+                a = time.perf_counter()
+                fn()
+                lat.append((time.perf_counter() - a) * 1e3)
+            return float(np.median(lat[10:]))
+
+        from instacart_next_order_recommendation_amd.recommender import Recommender
+        p50_rec_ms = p50_of(lambda: Recommender.recommend(mon, one_text, TOP_K))
+        p50_mon_ms = p50_of(lambda: mon.recommend(one_text, TOP_K, user_id="bench"))
+        same = Recommender.recommend(mon, one_text, TOP_K) == mon.recommend(one_text, TOP_K)
+        m = mon.last_metrics
+        mon_fields = {"tokens": len(mon.model.tokenizer([one_text])[0]), "results_equal_to_plain_recommend": bool(same),
+                      "query_embedding_time_ms": m.query_embedding_time_ms,
+                      "similarity_compute_time_ms": m.similarity_compute_time_ms, "total_latency_ms": m.total_latency_ms,
+                      "note": "MonitoredRecommender.recommend(str): host WordPiece + two replayed hipGraphs (encode | search) "
+                              "bracketed by HIP events (the three timing fields) + D2H of k results; catalog of 49,688 "
+                              "synthetic product texts encoded at construction"}
 
     if rank == 0:
         q_per_step = args.batch * world
@@ -453,6 +555,9 @@ def main() -> None:
                 if world > 1 else "single GPU",
             },
             "rehearsal_not_a_measurement": True if rehearsal else None,
+            "exchange_verified": exchange_verified,
+            "exchange_verified_note": None if exchange_verified is None else
+            "every rank: 64-query sample of the gathered batch searched against a replicated unsharded index, indices and scores bit-equal",
             "exchange": None if world == 1 else ("icrec_search_sharded (RCCL inside libicrec)" if comm is not None else
                                                  (comm_note or "torch.distributed collectives (gloo rehearsal)")),
             "p50_latency_ms_single_request": p50_ms,
@@ -461,6 +566,10 @@ def main() -> None:
             "with_two_stream_encode": two_stream,
             "exact_f32_gemm_mode": f32_leg,
             "from_text_in_host_memory": text_path,
+            "from_strings_pipelined": strings_pipelined,
+            "p50_latency_ms_recommend_from_string": p50_rec_ms,
+            "p50_latency_ms_monitored_recommend_from_string": p50_mon_ms,
+            "monitored_recommend": mon_fields,
             "catalog_index_build_ms": index_build_ms,
             "catalog_index_build_note": None if index_build_ms is None else
             f"encode {CATALOG_ROWS} products ({catalog_tokens} tokens, from ids in HBM) + normalise into a DeviceIndex",

@@ -168,6 +168,7 @@ ICREC_API int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32
                           int64_t row_offset, int device, int32_t storage, icrec_index** out);
 ICREC_API int icrec_index_destroy(icrec_index* idx);
 ICREC_API int64_t icrec_index_rows(const icrec_index* idx);
+ICREC_API int64_t icrec_index_row_offset(const icrec_index* idx); /* global number of the shard's first row */
 ICREC_API int32_t icrec_index_storage(const icrec_index* idx); /* ICREC_ROWS_* (-1: NULL handle) */
 ICREC_API int32_t icrec_index_dim(const icrec_index* idx);     /* embedding width (0: NULL handle)  */
 ICREC_API int32_t icrec_index_device(const icrec_index* idx);  /* HIP device ordinal (-1: NULL)     */
@@ -277,6 +278,26 @@ ICREC_API int icrec_search_sharded(icrec_index* idx, icrec_comm* comm, const flo
                          const int32_t* excl_idx_dev, const int32_t* excl_off_dev,
                          int64_t* out_idx_dev, float* out_score_dev,
                          void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The same collective with PER-RANK exclusion lists: the reference takes `exclude_product_ids` per request
+ * (serve_recommendations.py:216-225), and with data-parallel front-ends only the rank that received a request
+ * knows its list.  Every rank passes the exclusions of ITS n_local queries as GLOBAL row numbers; the library
+ * all-gathers them (offsets, then the ids padded to excl_cap) and each rank applies the ones inside its shard:
+ *     ncclAllGather(excl_off) + ncclAllGather(excl_rows)  -> shard-local CSR for the Q gathered queries (3 tiny kernels)
+ *     then as icrec_search_sharded
+ *   excl_rows_dev  int32[excl_cap]  GLOBAL rows, the CSR values of this rank's n_local queries: each query's rows
+ *                                   ascending and unique; entries past excl_off[n_local] are ignored
+ *   excl_off_dev   int32[n_local+1] offsets into excl_rows_dev (excl_off[n_local] <= excl_cap)
+ *   excl_cap       the padded length of every rank's id buffer: the SAME on every rank (a deployment constant, e.g.
+ *                  n_local x the API's per-request limit); 8 * world * excl_cap bytes of workspace
+ * Offsets outside [0, excl_cap] are clamped (a malformed list excludes less, never reads out of bounds). */
+ICREC_API size_t icrec_search_sharded_excl_workspace_bytes(const icrec_index* idx, const icrec_comm* comm,
+                                                 int32_t n_local_queries, int32_t k, int32_t excl_cap);
+ICREC_API int icrec_search_sharded_excl(icrec_index* idx, icrec_comm* comm, const float* q_local_dev,
+                              int32_t n_local_queries, int32_t k,
+                              const int32_t* excl_rows_dev, const int32_t* excl_off_dev, int32_t excl_cap,
+                              int64_t* out_idx_dev, float* out_score_dev,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Host tokenizer: the WordPiece stage of SentenceTransformer.encode           */

@@ -1,5 +1,7 @@
-"""A minimal asyncio HTTP/1.1 server for ASGI apps (keep-alive, Content-Length bodies, no chunked uploads,
-no TLS, no websockets).  uvicorn works with this app too (`uvicorn instacart_next_order_recommendation_amd.api.app:app`,
+"""A minimal asyncio HTTP/1.1 server for ASGI apps (keep-alive, Content-Length bodies, no TLS, no websockets).
+Request bodies are bounded (MAX_BODY_BYTES env, default 64 MiB: room for a 100,000-product corpus upload); a
+malformed or negative Content-Length is answered 400, an oversized one 413, `Transfer-Encoding: chunked` 501 and
+`Expect: 100-continue` gets its interim reply.  uvicorn stays the hardened option.  uvicorn works with this app too (`uvicorn instacart_next_order_recommendation_amd.api.app:app`,
 as the reference starts its own: `uvicorn src.api.main:app`); without httptools/uvloop in the image its pure-Python
 h11 parser costs more per request than FastAPI itself, so the multi-process server (serve.py) uses this one.
 One asyncio.Protocol per connection, requests on a connection handled in order (pipelining is not reordered).
@@ -7,12 +9,15 @@ One asyncio.Protocol per connection, requests on a connection handled in order (
 from __future__ import annotations
 
 import asyncio
+import os
 import socket
 from typing import Optional
 
+MAX_BODY_BYTES = int(os.getenv("MAX_BODY_BYTES", str(64 << 20)))
+
 _REASON = {200: b"OK", 400: b"Bad Request", 401: b"Unauthorized", 404: b"Not Found", 405: b"Method Not Allowed",
            413: b"Payload Too Large", 422: b"Unprocessable Entity", 500: b"Internal Server Error",
-           503: b"Service Unavailable"}
+           501: b"Not Implemented", 503: b"Service Unavailable"}
 
 
 class _Conn(asyncio.Protocol):
@@ -21,6 +26,7 @@ class _Conn(asyncio.Protocol):
         self.buf = bytearray()
         self.transport: Optional[asyncio.Transport] = None
         self.busy = False
+        self.continued = False  # "100 Continue" already sent for the request being received
         self.peer = ("0.0.0.0", 0)
 
     def connection_made(self, transport):
@@ -44,18 +50,30 @@ class _Conn(asyncio.Protocol):
         except ValueError:
             self.transport.close()
             return
-        headers, clen, keep = [], 0, True
+        headers, clen, keep, expect = [], 0, True, False
         for ln in lines[1:]:
             k, _, v = ln.partition(b":")
             k, v = k.strip().lower(), v.strip()
             headers.append((k, v))
             if k == b"content-length":
-                clen = int(v or 0)
+                if not v.isdigit():  # empty, negative, non-numeric: the framing of everything behind it is unknown
+                    return self._reject(400)
+                clen = int(v)
+                if clen > MAX_BODY_BYTES:
+                    return self._reject(413)
+            elif k == b"transfer-encoding" and v.lower() != b"identity":
+                return self._reject(501)
+            elif k == b"expect" and v.lower() == b"100-continue":
+                expect = True
             elif k == b"connection" and v.lower() == b"close":
                 keep = False
         total = head_end + 4 + clen
         if len(self.buf) < total:
+            if expect and not self.continued:
+                self.continued = True
+                self.transport.write(b"HTTP/1.1 100 Continue\r\n\r\n")
             return
+        self.continued = False
         body = bytes(self.buf[head_end + 4:total])
         del self.buf[:total]
         self.busy = True
@@ -64,6 +82,13 @@ class _Conn(asyncio.Protocol):
                  "path": path.decode("latin-1"), "raw_path": path, "query_string": query, "root_path": "",
                  "scheme": "http", "headers": headers, "client": self.peer, "server": ("icrec", 0), "state": {}}
         self.loop.create_task(self._handle(scope, body, keep))
+
+    def _reject(self, code: int) -> None:
+        """Answer a request whose framing cannot be honoured and close: nothing behind it can be parsed."""
+        self.buf.clear()
+        if self.transport is not None:
+            self.transport.write(b"HTTP/1.1 %d %s\r\ncontent-length: 0\r\nconnection: close\r\n\r\n" % (code, _REASON[code]))
+            self.transport.close()
 
     async def _handle(self, scope, body: bytes, keep: bool):
         sent = False

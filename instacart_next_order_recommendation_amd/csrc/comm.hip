@@ -97,6 +97,98 @@ static ShardWs shard_ws(const icrec_index* idx, int n_local, int world, int k) {
     return w;
 }
 
+// ---- per-rank exclusion lists -> the shard-local CSR icrec_search_partial takes (icrec_search_sharded_excl)
+struct ExclWs {
+    size_t off_all, rows_all, cnt, csr_off, csr_idx, inner, total;
+};
+static ExclWs excl_ws(const icrec_index* idx, int n_local, int world, int k, int cap) {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t Q = (size_t)n_local * world;
+    ExclWs w;
+    size_t o = 0;
+    w.off_all = o;  o += al((size_t)world * (n_local + 1) * 4);
+    w.rows_all = o; o += al((size_t)world * cap * 4);
+    w.cnt = o;      o += al(Q * 4);
+    w.csr_off = o;  o += al((Q + 1) * 4);
+    w.csr_idx = o;  o += al((size_t)world * cap * 4);
+    w.inner = o;
+    const size_t s = shard_ws(idx, n_local, world, k).total;
+    if (s == 0) { w.total = 0; return w; }
+    o += al(s);
+    w.total = o;
+    return w;
+}
+
+// gathered query g = (rank r, local query i): its ids are rows_all[r][lo .. hi), lo / hi from off_all[r][i], [i + 1]
+__device__ __forceinline__ void excl_segment(const int32_t* __restrict__ off_all, int n_local, int cap, int g, int& r,
+                                             int& lo, int& hi) {
+    r = g / n_local;
+    const int i = g - r * n_local;
+    lo = off_all[(size_t)r * (n_local + 1) + i];
+    hi = off_all[(size_t)r * (n_local + 1) + i + 1];
+    lo = lo < 0 ? 0 : (lo > cap ? cap : lo);
+    hi = hi < lo ? lo : (hi > cap ? cap : hi);
+}
+
+__global__ __launch_bounds__(256) void excl_count_kernel(const int32_t* __restrict__ off_all,
+                                                         const int32_t* __restrict__ rows_all, int n_local, int cap,
+                                                         int Q, int64_t row_lo, int64_t row_hi, int32_t* __restrict__ cnt) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= Q) return;
+    int r, lo, hi;
+    excl_segment(off_all, n_local, cap, g, r, lo, hi);
+    int c = 0;
+    for (int j = lo; j < hi; ++j) {
+        const int64_t v = rows_all[(size_t)r * cap + j];
+        c += (v >= row_lo && v < row_hi) ? 1 : 0;
+    }
+    cnt[g] = c;
+}
+
+// exclusive prefix sum of cnt[0 .. Q) -> off[0 .. Q]; one 1,024-thread workgroup, chunks of 1,024 with a carry
+__global__ __launch_bounds__(1024) void excl_scan_kernel(const int32_t* __restrict__ cnt, int Q, int32_t* __restrict__ off) {
+    __shared__ int part[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < Q; base += 1024) {
+        const int g = base + tid;
+        const int v = g < Q ? cnt[g] : 0;
+        int x = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) part[wave] = x;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += part[w];
+        const int carry = carry_s;
+        if (g < Q) off[g] = carry + wbase + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wbase + x;
+        __syncthreads();
+    }
+    if (tid == 0) off[Q] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void excl_fill_kernel(const int32_t* __restrict__ off_all,
+                                                        const int32_t* __restrict__ rows_all, int n_local, int cap,
+                                                        int Q, int64_t row_lo, int64_t row_hi,
+                                                        const int32_t* __restrict__ off, int32_t* __restrict__ idx) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= Q) return;
+    int r, lo, hi;
+    excl_segment(off_all, n_local, cap, g, r, lo, hi);
+    int o = off[g];
+    for (int j = lo; j < hi; ++j) {  // ascending global rows in -> ascending local rows out (the search kernel bisects)
+        const int64_t v = rows_all[(size_t)r * cap + j];
+        if (v >= row_lo && v < row_hi) idx[o++] = (int32_t)(v - row_lo);
+    }
+}
+
 }  // namespace icrec
 
 using namespace icrec;
@@ -192,6 +284,58 @@ int icrec_search_sharded(icrec_index* idx, icrec_comm* h, const float* q_local_d
         merged_from = keys_all;
     }
     return icrec_merge_topk(merged_from, c->comm ? c->world : 1, Q, k, out_idx_dev, out_score_dev, c->device, stream);
+}
+
+size_t icrec_search_sharded_excl_workspace_bytes(const icrec_index* idx, const icrec_comm* h, int32_t n_local, int32_t k,
+                                                 int32_t excl_cap) {
+    const Comm* c = reinterpret_cast<const Comm*>(h);
+    if (!idx || !c || n_local < 1 || k < 1 || excl_cap < 1) return 0;
+    return excl_ws(idx, n_local, c->world, k, excl_cap).total;
+}
+
+int icrec_search_sharded_excl(icrec_index* idx, icrec_comm* h, const float* q_local_dev, int32_t n_local, int32_t k,
+                              const int32_t* excl_rows_dev, const int32_t* excl_off_dev, int32_t excl_cap,
+                              int64_t* out_idx_dev, float* out_score_dev, void* ws, size_t ws_bytes, void* stream) {
+    Comm* c = reinterpret_cast<Comm*>(h);
+    ICREC_REQUIRE(idx && c && q_local_dev && out_idx_dev && out_score_dev && excl_rows_dev && excl_off_dev,
+                  "icrec_search_sharded_excl: NULL argument");
+    ICREC_REQUIRE(n_local >= 1 && k >= 1 && k <= ICREC_MAX_K && excl_cap >= 1, "icrec_search_sharded_excl: bad n_local/k/excl_cap (%d, %d, %d)", n_local, k, excl_cap);
+    ICREC_REQUIRE((int64_t)n_local * c->world < (1ll << 31) && (int64_t)excl_cap * c->world < (1ll << 31),
+                  "icrec_search_sharded_excl: too many queries / exclusions");
+    const ExclWs w = excl_ws(idx, n_local, c->world, k, excl_cap);
+    if (w.total == 0 || !ws || ws_bytes < w.total) {
+        set_error("icrec_search_sharded_excl: workspace too small (%zu < %zu)", ws_bytes, w.total);
+        return ICREC_ENOMEM;
+    }
+    ICREC_REQUIRE(icrec_index_device(idx) == c->device, "icrec_search_sharded_excl: index is on device %d, communicator on %d",
+                  icrec_index_device(idx), c->device);
+    ICREC_HIP(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    char* base = reinterpret_cast<char*>(ws);
+    int32_t* off_all = reinterpret_cast<int32_t*>(base + w.off_all);
+    int32_t* rows_all = reinterpret_cast<int32_t*>(base + w.rows_all);
+    int32_t* cnt = reinterpret_cast<int32_t*>(base + w.cnt);
+    int32_t* csr_off = reinterpret_cast<int32_t*>(base + w.csr_off);
+    int32_t* csr_idx = reinterpret_cast<int32_t*>(base + w.csr_idx);
+    const int32_t* off_use = excl_off_dev;
+    const int32_t* rows_use = excl_rows_dev;
+    if (c->comm) {
+        ICREC_NCCL(g_rccl.AllGather(excl_off_dev, off_all, (size_t)n_local + 1, ncclInt32, c->comm, st));
+        ICREC_NCCL(g_rccl.AllGather(excl_rows_dev, rows_all, (size_t)excl_cap, ncclInt32, c->comm, st));
+        off_use = off_all;
+        rows_use = rows_all;
+    }
+    const int world = c->comm ? c->world : 1;
+    const int Q = n_local * world;
+    const int64_t row_lo = icrec_index_row_offset(idx), row_hi = row_lo + icrec_index_rows(idx);
+    hipLaunchKernelGGL(excl_count_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, off_use, rows_use, n_local, excl_cap, Q,
+                       row_lo, row_hi, cnt);
+    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)cnt, Q, csr_off);
+    hipLaunchKernelGGL(excl_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, off_use, rows_use, n_local, excl_cap, Q,
+                       row_lo, row_hi, (const int32_t*)csr_off, csr_idx);
+    ICREC_HIP(hipGetLastError());
+    return icrec_search_sharded(idx, h, q_local_dev, n_local, k, csr_idx, csr_off, out_idx_dev, out_score_dev,
+                                base + w.inner, w.total - w.inner, stream);
 }
 
 }  // extern "C"

@@ -1299,6 +1299,7 @@ int icrec_index_destroy(icrec_index* h) {
 }
 
 int64_t icrec_index_rows(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->n_rows : 0; }
+int64_t icrec_index_row_offset(const icrec_index* h) { return h ? reinterpret_cast<const Index*>(h)->row_offset : 0; }
 
 int icrec_index_export(const icrec_index* h, float* rows_dev, void* stream) {
     const Index* ix = reinterpret_cast<const Index*>(h);

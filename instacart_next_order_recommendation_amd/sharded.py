@@ -91,19 +91,43 @@ class NativeComm:
 
     @classmethod
     def from_process_group(cls, device, group=None) -> "NativeComm":
-        """Bootstrap over an initialised torch.distributed group: rank 0 draws the id, a 128-byte broadcast
-        delivers it (the only use of torch.distributed on the product path)."""
+        """Bootstrap over an initialised torch.distributed group: rank 0 draws the id, a broadcast delivers it (the
+        only use of torch.distributed on the product path).
+
+        Every rank issues the SAME collective sequence whatever fails locally: (1) each rank loads librccl by
+        drawing an id of its own (local, no communication; only rank 0's is used); (2) rank 0 broadcasts
+        [status byte | 128-byte id]; (3) an all_reduce(MIN) of "librccl loaded and rank 0's id is valid" — when it
+        is 0 EVERY rank raises IcrecError and nobody enters ncclCommInitRank; (4) the collective
+        ncclCommInitRank.  A rank that dies inside (4) leaves the others waiting there: that is RCCL's contract and
+        cannot be repaired from outside.  The world > 1 RCCL path has run on a one-rank communicator only (no
+        multi-GPU box is available to the build); bench.py verifies its first real run against an unsharded search."""
+        from . import _native
+
         if not dist.is_initialized():
             return cls(0, 1, device, None)
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         if world == 1:
             return cls(0, 1, device, None)
         on_gpu = dist.get_backend(group) == "nccl"
-        t = torch.zeros(128, dtype=torch.uint8, device=torch.device(device) if on_gpu else "cpu")
-        if rank == 0:
-            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        where = torch.device(device) if on_gpu else torch.device("cpu")
+        my_id, err = None, ""
+        try:
+            my_id = cls.unique_id()  # dlopen(librccl) + ncclGetUniqueId, on every rank
+        except Exception as exc:  # noqa: BLE001 - reported through the collective below, never by skipping one
+            err = f"{type(exc).__name__}: {exc}"
+        t = torch.zeros(1 + _native.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0 and my_id is not None:
+            t[0] = 1
+            t[1:] = torch.frombuffer(bytearray(my_id), dtype=torch.uint8)
+        t = t.to(where)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(rank, world, device, bytes(t.cpu().numpy().tobytes()))
+        t = t.cpu()
+        ok = torch.tensor([1 if (my_id is not None and int(t[0]) == 1) else 0], dtype=torch.int32, device=where)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            raise _native.IcrecError("RCCL communicator not created: " + (err or (
+                "rank 0 could not draw the rendezvous id" if int(t[0]) != 1 else "librccl failed to load on another rank")))
+        return cls(rank, world, device, bytes(t[1:].numpy().tobytes()))
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -162,6 +186,67 @@ class ShardedSearch:
                                              P(self._ws), self._ws.numel(), st), "icrec_search_sharded")
         return idx, sc
 
+    DEFAULT_EXCL_PER_QUERY = 128  # default id capacity per local query of the exclusion exchange (excl_cap = n_local x this)
+
+    def _excl_cap(self, n_local: int, excl_cap: Optional[int]) -> int:
+        return int(excl_cap) if excl_cap else n_local * self.DEFAULT_EXCL_PER_QUERY
+
+    @staticmethod
+    def _local_csr(exclude_local, n_local: int, cap: int):
+        """This rank's per-query GLOBAL rows -> (rows int32[cap] zero-padded, off int32[n_local+1]) numpy arrays."""
+        import numpy as np
+
+        if len(exclude_local) != n_local:
+            raise ValueError(f"exclude_local has {len(exclude_local)} entries for {n_local} local queries")
+        off = np.zeros(n_local + 1, np.int32)
+        flat: list[int] = []
+        for i, e in enumerate(exclude_local):
+            flat.extend(sorted(set(int(v) for v in e)))
+            off[i + 1] = len(flat)
+        if len(flat) > cap:
+            raise ValueError(f"{len(flat)} excluded rows on this rank exceed excl_cap={cap} (the same constant on every rank)")
+        rows = np.zeros(cap, np.int32)
+        rows[:len(flat)] = flat
+        return rows, off
+
+    def _search_native_local_excl(self, q_local: torch.Tensor, k: int, exclude_local, excl_cap: Optional[int]):
+        """icrec_search_sharded_excl: every rank hands in the exclusions of ITS queries (global rows); the library
+        exchanges them (two more all-gathers) and applies each list on the shard that holds the rows."""
+        from . import _native
+
+        ix = self.backend.index
+        q = q_local.to(device=ix.device, dtype=torch.float32).contiguous()
+        n_local = int(q.shape[0])
+        Q = n_local * self.world
+        cap = self._excl_cap(n_local, excl_cap)
+        rows_h, off_h = self._local_csr(exclude_local, n_local, cap)
+        rows = torch.from_numpy(rows_h).to(ix.device)
+        off = torch.from_numpy(off_h).to(ix.device)
+        L = _native.lib()
+        need = int(L.icrec_search_sharded_excl_workspace_bytes(ix._h, self.comm._h, n_local, k, cap))
+        if need == 0:
+            raise _native.IcrecError(f"bad sharded search shape: n_local={n_local}, k={k}, excl_cap={cap}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=ix.device)
+        idx = torch.empty((Q, k), dtype=torch.int64, device=ix.device)
+        sc = torch.empty((Q, k), dtype=torch.float32, device=ix.device)
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        st = C.c_void_p(torch.cuda.current_stream(ix.device).cuda_stream)
+        _native.check(L.icrec_search_sharded_excl(ix._h, self.comm._h, P(q), n_local, k, P(rows), P(off), cap, P(idx), P(sc),
+                                                  P(self._ws), self._ws.numel(), st), "icrec_search_sharded_excl")
+        return idx, sc
+
+    def _gather_local_exclusions(self, exclude_local, n_local: int, excl_cap: Optional[int]):
+        """torch.distributed form of the same exchange: -> per gathered query (rank-major) the global rows."""
+        cap = self._excl_cap(n_local, excl_cap)
+        rows_h, off_h = self._local_csr(exclude_local, n_local, cap)
+        if self.world == 1:
+            rows_all, off_all = rows_h[None], off_h[None]
+        else:
+            rows_all = self._all_gather_rows(torch.from_numpy(rows_h)[None]).numpy()
+            off_all = self._all_gather_rows(torch.from_numpy(off_h)[None]).numpy()
+        return [rows_all[r, off_all[r, i]:off_all[r, i + 1]].tolist() for r in range(self.world) for i in range(n_local)]
+
     def _local_exclusions(self, exclude_global):
         if exclude_global is None:
             return None
@@ -182,9 +267,20 @@ class ShardedSearch:
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
         return q_local if self.world == 1 else self._all_gather_rows(q_local)
 
-    def search(self, q_local: torch.Tensor, k: int, exclude_global: Optional[Sequence[Iterable[int]]] = None):
+    def search(self, q_local: torch.Tensor, k: int, exclude_global: Optional[Sequence[Iterable[int]]] = None,
+               exclude_local: Optional[Sequence[Iterable[int]]] = None, excl_cap: Optional[int] = None):
         """q_local [Q/W, d] -> (idx int64 [Q, k] global rows, score float32 [Q, k]) on every rank.
-        `exclude_global`: per query (all Q of them, in gathered order) GLOBAL row numbers."""
+        `exclude_local`: the exclusions of THIS rank's queries only (per local query, GLOBAL row numbers) - what a
+        data-parallel front-end knows; they are exchanged with the queries (`excl_cap`: ids per rank, the same
+        constant on every rank, default n_local x 128).  Every rank must use the same form in a given call.
+        `exclude_global`: the replicated form - per query (all Q of them, in gathered order) GLOBAL row numbers,
+        identical on every rank; nothing is exchanged."""
+        if exclude_local is not None:
+            if exclude_global is not None:
+                raise ValueError("give exclusions either per local query (exclude_local) or replicated (exclude_global)")
+            if self.comm is not None:
+                return self._search_native_local_excl(q_local, k, exclude_local, excl_cap)
+            exclude_global = self._gather_local_exclusions(exclude_local, int(q_local.shape[0]), excl_cap)
         if self.comm is not None:
             return self._search_native(q_local, k, exclude_global)
         q_all = self.gather_queries(q_local)

@@ -139,6 +139,78 @@ def test_graph_fast_path_equals_plain_path(world, monkeypatch):
     assert Recommender(world["model_dir"], world["corpus_path"])._fast is None
 
 
+def test_monitored_recommender_runs_on_the_graph_path(world, monkeypatch, caplog):
+    """MonitoredRecommender.recommend (what the API constructs, reference src/api/main.py:73) replays the captured
+    request cut at the encode / search seam with HIP events around the two replays: same results as the plain
+    class's one-graph path and as the un-captured path, bit for bit; the three timing fields are filled; the
+    `recommendation_served` record carries the user id."""
+    import logging
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.recommender import MonitoredRecommender, Recommender
+
+    mon = MonitoredRecommender(world["model_dir"], world["corpus_path"])
+    assert mon._fast is not None
+    queries = ["[+1d w0h1] Milk.", world["queries"][0], "; ".join(syn.synthetic_user_contexts(8, seed=77))]
+    with caplog.at_level(logging.INFO, logger="recommender.metrics"):
+        for rep in range(2):
+            for q in queries:
+                for k, ex in [(5, None), (20, {"1", "2", "3"}), (5, set(mon.product_ids[:300]))]:
+                    got = mon.recommend(q, k, user_id="u7", exclude_product_ids=ex)
+                    assert got == Recommender.recommend(mon, q, k, ex), (q[:20], k)          # one-graph path
+                    assert got == mon.recommend_batch([q], k, [ex])[0], (q[:20], k)          # kernel by kernel
+                    m = mon.last_metrics
+                    assert m.user_id == "u7" and m.num_recommendations == len(got) and m.top_score == got[0][1]
+                    assert 0 < m.query_embedding_time_ms < 50 and 0 < m.similarity_compute_time_ms < 50
+                    assert m.total_latency_ms >= m.similarity_compute_time_ms
+    assert any(c.timed is not None for c in mon._fast._graphs.values())   # the split graphs were captured and used
+    served = [r for r in caplog.records if r.getMessage() == "recommendation_served"]
+    assert len(served) == 18 and all(r.user_id == "u7" for r in served)
+    # ICREC_USE_GRAPH=0: the event-timed kernel-by-kernel path, same results
+    monkeypatch.setenv("ICREC_USE_GRAPH", "0")
+    plain = MonitoredRecommender(world["model_dir"], world["corpus_path"])
+    assert plain._fast is None
+    assert plain.recommend(queries[1], 10, user_id="x") == mon.recommend(queries[1], 10)
+
+
+def test_two_different_batches_with_equal_split_point(world):
+    """encode_packed_host on two DIFFERENT batches of the same size whose first halves hold the same token count:
+    the second half's rebased cu_seqlens must come from the call's own sequence boundaries (an address-keyed cache
+    once handed the second batch the first batch's boundaries)."""
+    import torch
+
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+    from instacart_next_order_recommendation_amd.model_io import load_model_dir
+
+    lm = load_model_dir(world["model_dir"])
+    enc = DeviceEncoder(lm.weights, lm.shape, "cuda:0")
+    n = 2 * DeviceEncoder.SPLIT_MIN_SEQS
+    rng = np.random.default_rng(3)
+
+    def batch(lens_a, lens_b):
+        lens = np.concatenate([lens_a, lens_b]).astype(np.int32)
+        cu = np.zeros(n + 1, np.int32)
+        np.cumsum(lens, out=cu[1:])
+        ids = rng.integers(1000, lm.shape.vocab_size, size=int(cu[-1])).astype(np.int32)
+        return ids, cu
+
+    half = n // 2
+    first = rng.integers(120, 200, size=half)
+    assert first.sum() >= DeviceEncoder.SPLIT_MIN_TOKENS
+    b1 = batch(first, rng.integers(120, 200, size=half))
+    second_lens = rng.permutation(rng.integers(130, 256, size=half))     # different boundaries, longer rows
+    b2 = batch(rng.permutation(first), second_lens)                      # same n, same token count in the first half
+    assert b1[1][half] == b2[1][half] and not np.array_equal(b1[1], b2[1])
+    outs = []
+    for ids, cu in (b1, b2, b1):
+        got = enc.encode_packed_host(ids, cu)                             # two-stream split inside
+        want = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), int(np.diff(cu).max()))
+        assert torch.equal(got, want)
+        outs.append(got.clone())
+    assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
+    enc.close()
+
+
 def test_encode_without_flag_normalisation(world):
     """SentenceTransformer.encode(normalize_embeddings=False): one normalisation pass fewer.  The synthetic model
     directory has a Normalize module, so the output is still a unit vector and equals the default up to one

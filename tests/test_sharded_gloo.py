@@ -69,7 +69,10 @@ def _worker(rank: int, world: int, port: int, n_rows: int, q_total: int, k: int,
         excl = [[(7 * i) % n_rows, (13 * i + 1) % n_rows, 5] for i in range(q_total)]  # global rows
         ss = ShardedSearch(OracleBackend(P[lo:hi], lo), lo, hi)
         idx, sc = ss.search(torch.from_numpy(q[rank * per:(rank + 1) * per]), k, excl)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx.numpy(), sc=sc.numpy())
+        # the same exclusions handed in per rank (each rank knows only ITS queries' lists): exchanged, same result
+        idx2, sc2 = ss.search(torch.from_numpy(q[rank * per:(rank + 1) * per]), k,
+                              exclude_local=excl[rank * per:(rank + 1) * per], excl_cap=16)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx.numpy(), sc=sc.numpy(), idx2=idx2.numpy(), sc2=sc2.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -89,6 +92,20 @@ def test_two_rank_sharded_search_equals_unsharded(tmp_path):
         got = np.load(tmp_path / f"r{r}.npz")
         np.testing.assert_array_equal(got["idx"], want_i)   # every rank holds the full, identical result
         np.testing.assert_array_equal(got["sc"], want_s)
+        np.testing.assert_array_equal(got["idx2"], want_i)  # per-rank exclusion lists, exchanged
+        np.testing.assert_array_equal(got["sc2"], want_s)
+
+
+def test_local_exclusion_csr_rejects_overflow_and_bad_shapes():
+    P = syn.synthetic_embeddings(64, 384, seed=1)
+    ss = ShardedSearch(OracleBackend(P, 0), 0, 64)
+    q = torch.from_numpy(syn.synthetic_embeddings(2, 384, seed=2))
+    with pytest.raises(ValueError, match="excl_cap"):
+        ss.search(q, 5, exclude_local=[[1, 2, 3], [4]], excl_cap=3)
+    with pytest.raises(ValueError, match="local queries"):
+        ss.search(q, 5, exclude_local=[[1]])
+    with pytest.raises(ValueError, match="either"):
+        ss.search(q, 5, exclude_global=[[1], [2]], exclude_local=[[1], [2]])
 
 
 def test_single_process_degenerates_to_plain_search():

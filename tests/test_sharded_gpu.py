@@ -103,3 +103,85 @@ def test_native_rccl_world1_equals_plain_search():
     np.testing.assert_array_equal(idx2.cpu().numpy(), wi2 + 1000)
     np.testing.assert_array_equal(sc2.cpu().numpy(), ws2)
     comm.close()
+
+
+def test_native_per_rank_exclusions_world1():
+    """icrec_search_sharded_excl through a real one-rank RCCL communicator: the exclusions arrive as GLOBAL rows of
+    this rank's own queries, are all-gathered (offsets + padded ids), cut to the shard and turned into the local
+    CSR on the device - same bits as the replicated form and as the oracle, with a row offset."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.sharded import HipShardBackend, NativeComm, ShardedSearch
+    from oracle import oracle
+
+    dev = torch.device("cuda:0")
+    P = syn.synthetic_embeddings(6211, 384, seed=1)
+    q = syn.synthetic_embeddings(512, 384, seed=2)
+    comm = NativeComm(0, 1, dev, NativeComm.unique_id())
+    lo, hi = 1000, 5000  # the shard holds global rows [1000, 5000): ids outside it belong to other shards
+    be = HipShardBackend(torch.from_numpy(P[lo:hi]).to(dev), lo, dev)
+    ss = ShardedSearch(be, lo, hi, comm=comm)
+    qd = torch.from_numpy(q).to(dev)
+    rng = np.random.default_rng(5)
+    excl = [sorted(set(rng.integers(0, 6211, size=int(rng.integers(0, 40))).tolist())) if i % 4 else [] for i in range(512)]
+    idx, sc = ss.search(qd, 20, exclude_local=excl, excl_cap=512 * 40)
+    ridx, rsc = ss.search(qd, 20, exclude_global=excl)
+    assert torch.equal(idx, ridx) and torch.equal(sc, rsc)
+    wi, ws = oracle.search(q, P[lo:hi], 20, [[r - lo for r in e if lo <= r < hi] for e in excl], row_offset=lo)
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(sc.cpu().numpy(), ws)
+    # every query excludes its own best hit: the exchange really reaches the kernel
+    best = idx[:, 0].cpu().tolist()
+    idx2, _ = ss.search(qd, 20, exclude_local=[[b] for b in best])
+    assert not any(b in row for b, row in zip(best, idx2.cpu().tolist()))
+    assert torch.equal(idx2[:, :19], idx[:, 1:])
+    # no exclusions at all on this rank (other ranks may still have some): zero offsets
+    idx3, sc3 = ss.search(qd, 20, exclude_local=[[] for _ in range(512)])
+    pi, ps = ss.search(qd, 20)
+    assert torch.equal(idx3, pi) and torch.equal(sc3, ps)
+    comm.close()
+
+
+def test_configs3_sizes_4096_queries():
+    """BASELINE configs[3] at its own sizes on one GPU: (a) 4,096 queries over the whole 49,688-row catalog (filter
+    index, 8-query oracle sample, bit-equal to the exact index); (b) the 4,096 gathered queries over ONE
+    6,211-row shard (rows 6,211 .. 12,421) through icrec_search_sharded with a one-rank RCCL communicator."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.search import DeviceIndex
+    from instacart_next_order_recommendation_amd.sharded import HipShardBackend, NativeComm, ShardedSearch, shard_bounds
+    from oracle import oracle
+
+    dev = torch.device("cuda:0")
+    P = syn.synthetic_embeddings(49_688, 384, seed=1)
+    q = syn.synthetic_embeddings(4096, 384, seed=2)
+    qd = torch.from_numpy(q).to(dev)
+    Pd = torch.from_numpy(P).to(dev)
+    fi = DeviceIndex(Pd, dev, storage="f32+filter")
+    ei = DeviceIndex(Pd, dev, storage="f32")
+    idx, sc = fi.search(qd, 20)
+    xi, xs = ei.search(qd, 20)
+    assert torch.equal(idx, xi) and torch.equal(sc, xs)
+    sample = [0, 1, 511, 512, 2047, 2048, 4094, 4095]
+    wi, ws = oracle.search(q[sample], P, 20)
+    np.testing.assert_array_equal(idx[sample].cpu().numpy(), wi)
+    np.testing.assert_array_equal(sc[sample].cpu().numpy(), ws)
+    b = shard_bounds(49_688, 8)
+    assert b[1] - b[0] == 6211
+    lo, hi = b[1], b[2]
+    comm = NativeComm(0, 1, dev, NativeComm.unique_id())
+    be = HipShardBackend(Pd[lo:hi], lo, dev, storage="f32+filter")
+    ss = ShardedSearch(be, lo, hi, comm=comm)
+    si, s_sc = ss.search(qd, 20)
+    wi2, ws2 = oracle.search(q[sample], P[lo:hi], 20, row_offset=lo)
+    np.testing.assert_array_equal(si[sample].cpu().numpy(), wi2)
+    np.testing.assert_array_equal(s_sc[sample].cpu().numpy(), ws2)
+    # shard-level property at full size: each list is sorted (score desc, row asc), rows inside the shard
+    s_np, i_np = s_sc.cpu().numpy(), si.cpu().numpy()
+    assert ((i_np >= lo) & (i_np < hi)).all()
+    d = np.diff(s_np, axis=1)
+    assert (d <= 0).all() and ((d < 0) | (np.diff(i_np, axis=1) > 0)).all()
+    comm.close()
+    fi.close(); ei.close()
