@@ -778,8 +778,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                             fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
                         }
                     }
-                    wt_mma<1, 2>(S, wh[ks & 7], wl[ks & 7], fh[(VAR & 8) ? 0 : (ks & 1)], fl[(VAR & 8) ? 0 : (ks & 1)]);
-                    if (!(VAR & 4)) {  // straight-line refill: this chunk's k-step ks+8, or the next chunk's ks+8-24
+                    wt_mma<1, 2, (VAR & 64) != 0>(S, wh[ks & 7], wl[ks & 7], fh[(VAR & 8) ? 0 : (ks & 1)], fl[(VAR & 8) ? 0 : (ks & 1)]);
+                    if (!(VAR & 4) && !((VAR & 128) && (ks & 1))) {  // straight-line refill: this chunk's k-step ks+8, or the next chunk's ks+8-24
+                                                                    // (VAR 128, timing only: every second refill skipped = half the weight stream)
                         if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
                         else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
                     }
@@ -884,8 +885,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                     }
                     __builtin_amdgcn_sched_barrier(0);  // issue the next step's LDS reads before this step's 18 MFMAs
                 }
-                wt_mma<3, 2>(Y, wh[k2 & 3], wl[k2 & 3], fh[(VAR & 8) ? 0 : (k2 & 1)], fl[(VAR & 8) ? 0 : (k2 & 1)]);
-                if (!(VAR & 4)) {
+                wt_mma<3, 2, (VAR & 64) != 0>(Y, wh[k2 & 3], wl[k2 & 3], fh[(VAR & 8) ? 0 : (k2 & 1)], fl[(VAR & 8) ? 0 : (k2 & 1)]);
+                if (!(VAR & 4) && !((VAR & 128) && (k2 & 1))) {
                     int nk = c * 8 + k2 + 4;
                     nk = nk < KS2 ? nk : KS2 - 1;  // past the end: re-read the last fragment (never consumed)
                     w_load<3>(wh[k2 & 3], wl[k2 & 3], w2p, nk, lo8);

@@ -125,16 +125,35 @@ __device__ __forceinline__ half8 x_frag(const char* plane, int tt, int j, int r,
 // ---------------------------------------------------------------- one k-step of MFMAs
 // acc[i][tt] += W_i . X_tt^T over 16 k: (w_hi, x_hi), (w_lo, x_hi), (w_hi, x_lo) — the canonical order every
 // kernel of the engine uses, so a token's result is independent of which kernel / tile shape computed it.
-template <int NTW, int TTW>
+// SHAPE16 (tools/ffn_bench.hip only, TIMING ONLY - the results are meaningless): every 32x32x16 MFMA is issued as
+// two v_mfma_f32_16x16x32_f16 on quarters of the same accumulator with the same operand registers: the FLOPs, the
+// matrix-pipe cycles and the operand traffic of a 16x16x32 port of the engine without its data layout.
+template <int NTW, int TTW, bool SHAPE16 = false>
 __device__ __forceinline__ void wt_mma(f32x16 (&acc)[NTW][TTW], const half8 (&wh)[NTW], const half8 (&wl)[NTW],
                                        const half8 (&xh)[TTW], const half8 (&xl)[TTW]) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int tt = 0; tt < TTW; ++tt) {
-            acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[tt], acc[i][tt], 0, 0, 0);
-            acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[tt], acc[i][tt], 0, 0, 0);
-            acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[tt], acc[i][tt], 0, 0, 0);
+            if constexpr (SHAPE16) {
+                f32x4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = f32x4{acc[i][tt][4 * u], acc[i][tt][4 * u + 1], acc[i][tt][4 * u + 2], acc[i][tt][4 * u + 3]};
+                q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[tt], q[0], 0, 0, 0);
+                q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[tt], q[1], 0, 0, 0);
+                q[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[tt], q[2], 0, 0, 0);
+                q[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[tt], q[3], 0, 0, 0);
+                q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[tt], q[0], 0, 0, 0);
+                q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[tt], q[1], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][tt][4 * u + e] = q[u][e];
+            } else {
+                acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[tt], acc[i][tt], 0, 0, 0);
+                acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[tt], acc[i][tt], 0, 0, 0);
+                acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[tt], acc[i][tt], 0, 0, 0);
+            }
         }
 }
 

@@ -365,6 +365,10 @@ def test_filter_full_catalog_batch(torch_cuda):
     torch.cuda.synchronize()
     _native.timing_enable(False)
     assert torch.equal(ie, fi) and torch.equal(se, fs)
+    sample = [0, 255, 256, 777, 1023]   # and against the oracle on THIS index, not only against the exact HIP path
+    wi, ws = _oracle().search(q[sample], P, 20)
+    np.testing.assert_array_equal(fi[sample].cpu().numpy(), wi)
+    np.testing.assert_array_equal(fs[sample].cpu().numpy(), ws)
     fallback_ms, n_fb = _native.timing_query(4)
     exact_ms, _ = _native.timing_query(0)
     assert n_fb == 1 and fallback_ms < 0.1 * exact_ms, (fallback_ms, exact_ms)  # exited at once: nothing was flagged

@@ -132,13 +132,13 @@ def test_native_per_rank_exclusions_world1():
     np.testing.assert_array_equal(idx.cpu().numpy(), wi)
     np.testing.assert_array_equal(sc.cpu().numpy(), ws)
     # every query excludes its own best hit: the exchange really reaches the kernel
-    best = idx[:, 0].cpu().tolist()
+    pi, ps = ss.search(qd, 20)
+    best = pi[:, 0].cpu().tolist()
     idx2, _ = ss.search(qd, 20, exclude_local=[[b] for b in best])
     assert not any(b in row for b, row in zip(best, idx2.cpu().tolist()))
-    assert torch.equal(idx2[:, :19], idx[:, 1:])
+    assert torch.equal(idx2[:, :19], pi[:, 1:])
     # no exclusions at all on this rank (other ranks may still have some): zero offsets
     idx3, sc3 = ss.search(qd, 20, exclude_local=[[] for _ in range(512)])
-    pi, ps = ss.search(qd, 20)
     assert torch.equal(idx3, pi) and torch.equal(sc3, ps)
     comm.close()
 

@@ -243,6 +243,19 @@ int main(int argc, char** argv) {
         if (T == T0 || T == 131072) {
             FFN2(1); FFN2(4); FFN2(5); FFN2(13); FFN2(16);
         }
+        if (T == 131072) {  // round-3 experiments, interleaved: MFMA shape (VAR 64, timing only) and half the weight stream (VAR 128)
+            std::vector<Cand> cs;
+            const int nb = (T + 63) / 64;
+#define CANDF(V, NAME) { auto kern = ffn_fused2_kernel<V>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS); \
+              cs.push_back({NAME, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
+            CANDF(0, "ffn_fused2 product")
+            CANDF(64, "ffn_fused2 16x16x32 issue (timing only)")
+            CANDF(128, "ffn_fused2 half the weight loads (timing only)")
+            CANDF(192, "ffn_fused2 16x16x32 + half the weight loads")
+            CANDF(4, "ffn_fused2 no in-loop weight loads")
+            CANDF(68, "ffn_fused2 16x16x32 + no in-loop weight loads")
+            compare(cs, ffn_flops, 11);
+        }
         reinit();
         timeit("qkv wt_linear<3,2,2,0> N=1152", [&] {
             hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
