@@ -121,9 +121,10 @@ def load_traffic(kernel_key: str):
 
 
 def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens: int) -> dict:
-    """Roofline entry for the dominant kernel.  f16x3 mode: the fused FFN kernel (FFN-up + GELU + FFN-down + residual +
-    LayerNorm, 6 launches per step); f32 mode: the FFN up-projection GEMM.  `achieved` counts ALGORITHMIC FLOPs once,
-    whatever the arithmetic (the 3-term split issues 3 MFMAs per product and is priced against 2500/3 TFLOP/s)."""
+    """Roofline entry for the dominant kernel.  f16x3 mode: the fused post-attention kernel of a layer (attention-output
+    projection + residual + LayerNorm, then FFN-up + GELU + FFN-down + residual + LayerNorm; 6 launches per step);
+    f32 mode: the FFN up-projection GEMM.  `achieved` counts ALGORITHMIC FLOPs once, whatever the arithmetic (the
+    3-term split issues 3 MFMAs per product and is priced against 2500/3 TFLOP/s)."""
     if mode == "f32":
         traffic, note = load_traffic("linear_kernel_gelu")
         return {"kernel": "linear_kernel<128x128, GELU> (FFN up-projection, v_mfma_f32_32x32x2_f32)",
@@ -132,28 +133,28 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
                 "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
     peak = PEAK_F16_MFMA_TFLOPS / 3.0
     traffic, note = load_traffic("ffn_fused2_kernel")
-    return {"kernel": "ffn_fused2_kernel (FFN-up + erf-GELU + FFN-down + residual + LayerNorm on chip; "
-                      "3x v_mfma_f32_32x32x16_f16 per product, weights streamed L2 -> registers)",
+    w_bytes = (2 * 1536 * 384 + 384 * 384) * 2 * 2  # W1, W2, Wo as packed hi/lo f16 fragments
+    l2_bytes = (tokens // 64) * (w_bytes + 64 * 384 * 4 * 2 + 6 * 1024)
+    return {"kernel": "ffn_fused2_kernel<0, AO> (attention-out + residual + LayerNorm, then FFN-up + erf-GELU + FFN-down + "
+                      "residual + LayerNorm, all on chip; 3x v_mfma_f32_16x16x32_f16 per product, weights streamed L2 -> registers)",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "peak_note": "fp32-accurate product = 3 f16 MFMAs, so the algorithm's MFMA roof is 2500/3 TFLOP/s of "
                          "algorithmic FLOPs; against the raw f16 dense peak the fraction is frac_of_f16_dense_peak",
             "frac_of_f16_dense_peak": achieved / PEAK_F16_MFMA_TFLOPS,
             "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
-            "algorithmic_bytes": tokens * 384 * (4 + 4) + 2 * 2 * 1536 * 384 * 2,
-            "algorithmic_bytes_note": "x planes in (2 x 2 B/elt: GEMM operand and residual at once) + x planes out, + the "
-                                      "layer's packed W1/W2 fragments once",
-            "ceiling_note": "a registers-only loop of the same MFMA instruction sustains 2,012 TFLOP/s f16 dense on this chip "
-                            "(tools/mfma_peak.hip, profiles/r02_mfma_sustained_rate.txt: the clock falls under matrix load), i.e. "
-                            "671 TFLOP/s of f16x3 products: frac_of_measured_mfma_ceiling prices the launch against that",
-            "frac_of_measured_mfma_ceiling": achieved / (2012.0 / 3.0),
-            # what actually sets the time: every 64-token workgroup pulls the layer's W1/W2 fragments
-            # (4.72 MB) + its planes through its vector L1; the chip delivers ~12 TB/s of such requests
-            "l2_stream": {"bytes_per_launch": (tokens // 64) * (2 * 2 * 1536 * 384 * 2 + 64 * 384 * 4 + 3 * 1024),
-                          "TBps_at_this_launch_time": ((tokens // 64) * (2 * 2 * 1536 * 384 * 2 + 64 * 384 * 4 + 3 * 1024)) / (ms * 1e-3) / 1e12
-                          if ms > 0 else None,
-                          "note": "L2 -> L1 requests per launch (PMC TCP_TCC_READ_REQ x 128 B: 10.2 GB, "
-                                  "profiles/r02_pmc_l2_stream.txt); the resident QKV kernel (4.1 GB / 0.33 ms) and the resident "
-                                  "search pass at 10 M rows (246 GB / 19.6 ms) run at the same 12-12.5 TB/s"},
+            "algorithmic_bytes": tokens * 384 * (4 + 4 + 4) + w_bytes,
+            "algorithmic_bytes_note": "context planes in + x planes in (residual) + x planes out (2 x 2 B/elt each), + the "
+                                      "layer's packed Wo/W1/W2 fragments once",
+            "ceiling_note": "a registers-only loop of the same MFMA instruction on RANDOM operands sustains 1,970 TFLOP/s f16 "
+                            "dense on this chip at 1.95 GHz (tools/mfma_shape.hip, profiles/r03_mfma_shape_microbench.txt; the "
+                            "32x32x16 form the engine used before: 1,710 at 1.69 GHz; both reach 2,450 on all-zero operands): "
+                            "the clock falls under matrix load, i.e. 657 TFLOP/s of f16x3 products is the measured ceiling",
+            "frac_of_measured_mfma_ceiling": achieved / (1970.0 / 3.0),
+            # every 64-token workgroup pulls the layer's Wo/W1/W2 fragments + its planes through its vector L1
+            "l2_stream": {"bytes_per_launch": l2_bytes,
+                          "TBps_at_this_launch_time": l2_bytes / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                          "note": "L2 -> L1 bytes per launch by construction (one pass over the layer's fragments per 64-token "
+                                  "workgroup); PMC TCP_TCC_READ_REQ of the committed profile agrees (profiles/r03_pmc_l2_stream.txt)"},
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
 
@@ -524,8 +525,9 @@ def main() -> None:
             _native.check(_native.lib().icrec_encode_batch_split(enc._h, total_tokens, C.byref(t_main), C.byref(t_tail)),
                           "icrec_encode_batch_split")
         ffn_tokens = int(t_main.value)
-        # algorithmic FLOPs per timed launch: FFN-up only in f32 mode, up + down in the fused kernel
-        ffn_flops = (2.0 if enc.gemm_mode == "f32" else 4.0) * ffn_tokens * shape.hidden * shape.intermediate
+        # algorithmic FLOPs per timed launch: FFN-up only in f32 mode; attention-out + FFN-up + FFN-down in the fused kernel
+        ffn_flops = 2.0 * ffn_tokens * shape.hidden * shape.intermediate if enc.gemm_mode == "f32" else \
+            ffn_tokens * (4.0 * shape.hidden * shape.intermediate + 2.0 * shape.hidden * shape.hidden)
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12 if ffn_ms > 0 else 0.0
         out = {
             "metric": "recommend_qps_top20_49k7_catalog" if args.workload == "49k7" else "recommend_qps_top20_10m_catalog",

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm_x3.h"
 #include "wt_gemm.h"
+#include "encoder_x3.h"
 
 namespace icrec {
 
@@ -112,57 +113,6 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const float* __restrict__ a
 // GELU is the exact erf form (tf:336, ACT2FN["gelu"]).
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// erf for the f16x3 GELU epilogue: branch-free, one v_exp_f32.  |x| <= 0.921875: x * P6(x^2); else
-// sign(x) * (1 - 2^Q8(min(|x|, 4))).  Coefficients: Chebyshev fits (tools/fit_erf.py); checked over 620k points
-// with fma emulation: max |error| 1.1e-7, max relative error 2.8 ulp — the same class as the library erff, at
-// about half its instruction count (the library version carries a full expf range reduction and two branches).
-__device__ __forceinline__ float erf_fast(float x) {
-    const float t = fminf(fabsf(x), 4.0f), s = x * x;
-    float a = 8.392696624e-05f;
-    a = fmaf(a, s, -8.148506071e-04f);
-    a = fmaf(a, s, 5.201591808e-03f);
-    a = fmaf(a, s, -2.685964751e-02f);
-    a = fmaf(a, s, 1.128370053e-01f);
-    a = fmaf(a, s, -3.761263411e-01f);
-    a = fmaf(a, s, 1.128379167e+00f);
-    float b = 2.327214131e-06f;
-    b = fmaf(b, t, -6.574532254e-05f);
-    b = fmaf(b, t, 8.549435650e-04f);
-    b = fmaf(b, t, -6.837534407e-03f);
-    b = fmaf(b, t, 3.803287522e-02f);
-    b = fmaf(b, t, -1.586590115e-01f);
-    b = fmaf(b, t, -9.116990640e-01f);
-    b = fmaf(b, t, -1.630481967e+00f);
-    b = fmaf(b, t, 4.364755836e-04f);
-    const float far = copysignf(1.0f - __builtin_amdgcn_exp2f(b), x);
-    return t <= 0.921875f ? x * a : far;
-}
-__device__ __forceinline__ float gelu_erf_fast(float x) { return x * 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
-
-// erf-GELU of the f16x3 engine, times the activation plane scale (16): one polynomial, one v_exp_f32, 16 VALU.
-//   gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2),     erfc(t / sqrt 2) = 2^Q10(min(t, 5.75))
-// (x >= 0: x - 0.5 x erfc = 0.5 x (1 + erf);  x < 0: 0.5 x erfc(|z|) = 0.5 x (1 + erf(z)).)  Only ABSOLUTE accuracy of
-// erfc matters here - it multiplies |x| and is added to a term of the size of x - so the separate small-|x| branch of
-// erf_fast (kept for relative accuracy of erf itself) is not needed.  Q10: Chebyshev fit of log2(erfc(t / sqrt 2)) on
-// [0, 5.75] (tools/fit_erf.py --gelu); in emulated fp32 fma arithmetic over 440k points: max |error| 2.4e-7 (half an
-// ulp at x = 4.3), relative error <= 1.05e-6 wherever |gelu| > 1e-3.
-__device__ __forceinline__ float gelu16_wt(float x) {
-    const float t = fminf(fabsf(x), 5.75f);
-    float q = -1.428101063e-08f;
-    q = fmaf(q, t, 4.683960178e-07f);
-    q = fmaf(q, t, -6.560040814e-06f);
-    q = fmaf(q, t, 4.923233760e-05f);
-    q = fmaf(q, t, -1.793856253e-04f);
-    q = fmaf(q, t, -2.251562182e-04f);
-    q = fmaf(q, t, 7.249582803e-03f);
-    q = fmaf(q, t, -5.267105742e-02f);
-    q = fmaf(q, t, -4.591336602e-01f);
-    q = fmaf(q, t, -1.151116827e+00f);
-    q = fmaf(q, t, 2.960897358e-07f);
-    const float e = __builtin_amdgcn_exp2f(q);
-    return fmaf(fabsf(x) * -8.0f, e, fmaxf(x * 16.0f, 0.0f));
-}
-
 template <class Cfg, bool GELU>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __restrict__ A, int M, int K,
                                                                  const float* __restrict__ W, int N,
@@ -194,1188 +144,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void linear_kernel(const float* __
                     out[row * N + col] = v;
                 }
             }
-    }
-}
-
-// ---------------------------------------------------------------- residual stream + LayerNorm of the f16x3 engine
-// In f16x3 mode the residual stream x lives in HBM ONLY as its two f16 planes (xh, xl: 16 x to 22 significant bits,
-// wt_gemm.h) — the planes every GEMM reads anyway.  The two LayerNorm sites of a layer (tf:292 attention output,
-// tf:350 FFN output: LN(dense(.) + bias + x)) start their accumulators from the residual instead of adding it at
-// the end:
-//     acc0 = fmaf(float(xh) + float(xl), 1024, bias * 2^14)      (hi + lo is exact in fp32; one rounding)
-//     acc  = acc0 + the k-steps of the GEMM, ascending           (units of 2^-14, like every accumulator of the engine)
-//     v    = acc * 2^-14                                         (exact)
-// then the engine's LayerNorm order over the 384 features of a token.  Wave q (0..3 of the waves holding
-// accumulators) owns features q*96 .. q*96+95: lane (r, h) holds, for token tile tt, the 48 values of token
-// tt*32 + r at features q*96 + i*32 + 8g + 4h + j (i < 3, g < 4, j < 4):
-//   part(q, h) = sum over (i, g, j), i outermost, of v            sequential fp32 adds from 0
-//   sum        = ((P0 + P1) + P2) + P3,   Pq = part(q, 0) + part(q, 1)
-//   mean = sum / 384;   d = v - mean;   the same tree over fmaf(d, d, .) chains;   var = that / 384
-//   y = fmaf(d * (1 / sqrtf(var + eps)), gamma, beta);   planes = split(16 y)
-// (ln_wt_kernel is the unfused form with the same order — same bits.)  Compared with an fp32 copy of x beside the
-// planes this drops 8 of the 12 bytes per element every LayerNorm site moved, and the residual needs no global
-// read where the planes are already in LDS (fused FFN).
-//
-// Global memory is touched only by coalesced accesses: a lane-per-token access pattern costs 4x the whole K loop
-// (in-kernel stamps: 73k cycles per block).  Each wave transposes its own [32 tokens x 96 features] of one plane
-// through a PRIVATE 6.5 KB LDS tile (rows of 192 B + 16 B pad): no workgroup barrier, 192 contiguous bytes per
-// token row on the global side.  LDS instructions of one wave execute in order; lds_order() keeps the compiler
-// from reordering across the hand-over and waits for the data.
-constexpr int LNT_ROW = 208;                        // bytes per tile row: 96 halfs + 16 B
-constexpr int LNT_TILE = 32 * LNT_ROW;              // one wave's tile
-constexpr int LNT_RED = 2 * 64 * 4 * 4;             // the two 4-partial exchanges: [2][64 tokens][4 waves] floats
-constexpr int LNT_PAR = 2 * 384 * 4;                // gamma, beta
-constexpr int LNT_BYTES = LNT_RED + 4 * LNT_TILE + LNT_PAR;   // 31,744 B
-
-__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ float res_init_val(_Float16 hi, _Float16 lo, float b) {
-    return fmaf((float)hi + (float)lo, WT_SW, b * (WT_SA * WT_SW));
-}
-
-// acc0 of a [96-feature x 64-token] wave tile from the residual planes in global memory.  `tile`: this wave's
-// LNT_TILE bytes of LDS.
-__device__ __forceinline__ void wt_res_init_global(f32x16 (&acc)[3][2], int q, const float* __restrict__ bias,
-                                                   const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
-                                                   int64_t m0, int64_t T, char* tile) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    u32x4 v[2][2][6];
-    int lpos[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {  // 16-B chunk f of the wave's [32 rows][12 chunks]: 12 lanes cover one row's 192 B
-        const int f = lane + 64 * k, row = f / 12, c = f - row * 12;
-        lpos[k] = row * LNT_ROW + c * 16;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            int64_t g = m0 + tt * 32 + row;
-            g = g < T ? g : T - 1;
-            const int64_t off = g * 384 + q * 96 + c * 8;
-            v[tt][0][k] = *reinterpret_cast<const u32x4*>(xh + off);
-            v[tt][1][k] = *reinterpret_cast<const u32x4*>(xl + off);
-        }
-    }
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x4*>(tile + lpos[k]) = v[tt][pl][k];
-            lds_order();
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int fl = i * 32 + 8 * g + 4 * h;
-                    const half4 a = *reinterpret_cast<const half4*>(tile + r * LNT_ROW + fl * 2);
-                    if (pl == 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][tt][4 * g + j] = (float)a[j];
-                    } else {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + q * 96 + fl);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)  // float(hi) + float(lo) is exact
-                            acc[i][tt][4 * g + j] = fmaf(acc[i][tt][4 * g + j] + (float)a[j], WT_SW, b[j] * (WT_SA * WT_SW));
-                    }
-                }
-            lds_order();
-        }
-}
-
-// The same for the single-tile waves of the small-batch kernels: 8-byte loads straight from global memory (a
-// handful of tokens: latency, not bandwidth).
-__device__ __forceinline__ void wt_res_init_direct(f32x16 (&acc)[1][1], int nt0, const float* __restrict__ bias,
-                                                   const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
-                                                   int N, int64_t m0, int64_t T) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    int64_t tok = m0 + r;
-    tok = tok < T ? tok : T - 1;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int feat = nt0 * 32 + 8 * g + 4 * h;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
-        const half4 a = *reinterpret_cast<const half4*>(xh + tok * N + feat);
-        const half4 d = *reinterpret_cast<const half4*>(xl + tok * N + feat);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][0][4 * g + j] = res_init_val(a[j], d[j], b[j]);
-    }
-}
-
-// this thread's 16 bytes of the [gamma | beta] table wt_ln_out keeps in LDS (threads 0 .. 191 of the callers)
-__device__ __forceinline__ f32x4 wt_ln_par_load(const float* __restrict__ gam, const float* __restrict__ bet, int ptid) {
-    const int t = ptid < 192 ? ptid : 0;
-    return *reinterpret_cast<const f32x4*>((t < 96 ? gam : bet - 384) + 4 * t);
-}
-
-// LayerNorm of a block's accumulators (acc = residual + bias + dense, in units of 2^-14) -> the two planes of x.
-// NT threads call; `active` = this wave holds accumulators (wave-uniform), `sync` = the workgroup barrier.
-// lds: LNT_BYTES.  ptid: index of the thread among the callers (0 .. 191 must be present).
-template <class Sync>
-__device__ __forceinline__ void wt_ln_out(f32x16 (&acc)[3][2], bool active, int q, _Float16* __restrict__ xh,
-                                          _Float16* __restrict__ xl, int64_t m0, int64_t T,
-                                          const float* __restrict__ gam, const float* __restrict__ bet, float eps,
-                                          char* lds, Sync sync, int ptid, int salt = 0,
-                                          const f32x4* par_pre = nullptr) {
-    // salt: 0, opaque to the compiler when the call sits in a loop - otherwise the per-lane addresses below are
-    // hoisted out of the loop and held (or spilled) across it
-    float* const red = reinterpret_cast<float*>(lds);
-    char* const tile = lds + LNT_RED + q * LNT_TILE;
-    float* const par = reinterpret_cast<float*>(lds + LNT_RED + 4 * LNT_TILE);
-    const int lane = (threadIdx.x & 63) + salt, r = lane & 31, h = lane >> 5;
-    ICREC_STAMP(0, 32); ICREC_STAMP(4, 32);
-    // gamma / beta -> LDS (visible after the first barrier): each lane needs the 48 values of its half of the wave's 96
-    // features, the same in every lane of the half - as vector loads that is 96 x 1 KB through the texture path per wave
-    // for 768 distinct bytes (measured: the normalise + write-out phase was bound by them)
-    // par_pre: the caller loaded this thread's 16 bytes earlier (wt_ln_par_load), off the critical path
-    if (ptid < 192) *reinterpret_cast<f32x4*>(par + 4 * ptid) = par_pre ? *par_pre : wt_ln_par_load(gam, bet, ptid);
-    if (active) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            float part = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float v = acc[i][p][e] * WT_UNSCALE;
-                    acc[i][p][e] = v;
-                    part = part + v;
-                }
-            part = part + __shfl_xor(part, 32, 64);  // Pq (a + b == b + a exactly: both halves hold the same bits)
-            if (h == 0) red[(p * 32 + r) * 4 + q] = part;
-        }
-    }
-    ICREC_STAMP(0, 33); ICREC_STAMP(4, 33);
-    sync();
-    if (active) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + (p * 32 + r) * 4);
-            const float mean = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
-            float sq = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float d = acc[i][p][e] - mean;
-                    acc[i][p][e] = d;
-                    sq = fmaf(d, d, sq);
-                }
-            sq = sq + __shfl_xor(sq, 32, 64);
-            if (h == 0) red[256 + (p * 32 + r) * 4 + q] = sq;
-        }
-    }
-    ICREC_STAMP(0, 34); ICREC_STAMP(4, 34);
-    sync();
-    ICREC_STAMP(0, 35); ICREC_STAMP(4, 35);
-    if (active) {
-        // chunk k of this lane in the flat [32 rows][12 x 16 B] view of a tile: row = f / 12, c = f % 12, f = lane + 64 k
-        auto flat = [&](int k, int& row, int& c) {
-            const int f = lane + 64 * k;
-            row = (f * 43691) >> 19;  // f / 12 for f < 384
-            c = f - row * 12;
-        };
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + 256 + (p * 32 + r) * 4);
-            const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
-            const float rstd = 1.0f / sqrtf(var + eps);
-            const int64_t t0 = m0 + p * 32;
-            half4 lo[3][4];
-            // the hi plane goes straight into the tile; lo waits in registers for its turn
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(par + feat);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(par + 384 + feat);
-                    f32x4 y;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][p][4 * g + j] * rstd, gm[j], bt[j]);
-                    half4 hi;
-                    split_act4(y, hi, lo[i][g]);
-                    *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = hi;
-                }
-            ICREC_STAMP(0, 37 + 3 * p); ICREC_STAMP(4, 37 + 3 * p);
-            lds_order();
-            u32x4 o[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int row, c;
-                flat(k, row, c);
-                o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + c * 16);
-            }
-            lds_order();
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) *reinterpret_cast<half4*>(tile + r * LNT_ROW + (i * 32 + 8 * g + 4 * h) * 2) = lo[i][g];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {  // the hi rows leave while the lo tile is written
-                int row, c;
-                flat(k, row, c);
-                if (t0 + row < T) *reinterpret_cast<u32x4*>(xh + (t0 + row) * 384 + q * 96 + c * 8) = o[k];
-            }
-            lds_order();
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int row, c;
-                flat(k, row, c);
-                o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + c * 16);
-            }
-            lds_order();
-            ICREC_STAMP(0, 38 + 3 * p); ICREC_STAMP(4, 38 + 3 * p);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int row, c;
-                flat(k, row, c);
-                if (t0 + row < T) *reinterpret_cast<u32x4*>(xl + (t0 + row) * 384 + q * 96 + c * 8) = o[k];
-            }
-            ICREC_STAMP(0, 39 + 3 * p); ICREC_STAMP(4, 39 + 3 * p);
-        }
-    }
-    ICREC_STAMP(0, 36); ICREC_STAMP(4, 36);
-}
-
-// The unfused form of the same LayerNorm (small batches; ICREC_FUSE=0): planes(x) <- LN(a), `a` = dense(.) + bias +
-// residual as the EPI 2 GEMM wrote it.  8 threads per token: thread (q, h) sums its 48 values in (i, g, j) order,
-// the 8 partials are combined by shuffles in the fixed tree of wt_ln_out.
-__global__ __launch_bounds__(256) void ln_wt_kernel(const float* __restrict__ a, int T, const float* __restrict__ gam,
-                                                    const float* __restrict__ bet, float eps,
-                                                    _Float16* __restrict__ xh, _Float16* __restrict__ xl) {
-    const int tid = threadIdx.x, slot = tid & 7, q = slot >> 1, h = slot & 1;
-    int64_t tok = (int64_t)blockIdx.x * 32 + (tid >> 3);
-    const bool ok = tok < T;
-    tok = ok ? tok : (int64_t)T - 1;
-    f32x4 v[3][4];
-    float part = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v[i][g] = *reinterpret_cast<const f32x4*>(a + tok * 384 + q * 96 + i * 32 + 8 * g + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part = part + v[i][g][j];
-        }
-    const int base = (tid & 63) & ~7;  // first lane of this token's 8 threads
-    auto tree = [&](float p) {  // ((P0 + P1) + P2) + P3 with Pq = part(q,0) + part(q,1); every lane gets the same bits
-        p = p + __shfl_xor(p, 1, 64);
-        const float p0 = __shfl(p, base, 64), p1 = __shfl(p, base + 2, 64), p2 = __shfl(p, base + 4, 64),
-                    p3 = __shfl(p, base + 6, 64);
-        return ((p0 + p1) + p2) + p3;
-    };
-    const float mean = tree(part) / 384.0f;
-    float sq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = v[i][g][j] - mean;
-                v[i][g][j] = d;
-                sq = fmaf(d, d, sq);
-            }
-    const float var = tree(sq) / 384.0f;
-    const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int feat = q * 96 + i * 32 + 8 * g + 4 * h;
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + feat);
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + feat);
-            f32x4 y;
-            half4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = fmaf(v[i][g][j] * rstd, gm[j], bt[j]);
-            split_act4(y, hi, lo);
-            if (ok) {
-                *reinterpret_cast<half4*>(xh + tok * 384 + feat) = hi;
-                *reinterpret_cast<half4*>(xl + tok * 384 + feat) = lo;
-            }
-        }
-}
-
-constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 16-B accesses of consecutive tokens hit distinct banks)
-
-// ---------------------------------------------------------------- f16x3 linear layers (wt_gemm.h)
-// out^T = W . X^T with the weights streamed straight from L2 into registers (packed fragment order) and the
-// token slab staged through LDS.  Block = 4 waves; wave q owns NTW 32-feature tiles x TTW 32-token tiles.
-//   EPI 0: out fp32 [T, N] = acc * 2^-14 + bias           (QKV)
-//   EPI 1: erf-GELU (tf:336), result as f16 hi/lo planes   (FFN-up of small batches)
-//   EPI 2: accumulators start from residual + bias (planes rh / rl, row stride N), out fp32 = acc * 2^-14: the
-//          LayerNorm input of attention-out / FFN-down for small batches (ln_wt_kernel follows)
-// Each lane holds 4 consecutive features of one token per register group: 16-B (fp32) / 8-B (planes) stores.
-template <int NTW, int TTW, int D, int EPI>
-__global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __restrict__ Xh,
-                                                           const _Float16* __restrict__ Xl, int T, int K,
-                                                           const _Float16* __restrict__ Wp, int N,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           _Float16* __restrict__ oh, _Float16* __restrict__ ol,
-                                                           int n_blocks_n) {
-    constexpr bool STAGED = (NTW == 3 && TTW == 2 && EPI != 1);  // batch form: results leave through an LDS stage, coalesced
-    constexpr int SM = (STAGED && 32 * LN_LD * 4 > XRing<TTW>::BYTES) ? 32 * LN_LD * 4 : XRing<TTW>::BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SM];
-    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-    // the n_blocks_n workgroups that read the same token rows get consecutive logical ids = the same XCD = one L2
-    // (PMC: without the remap the QKV launch fetched its activations three times, 930 MB instead of ~330 MB)
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
-    const int64_t m0 = (int64_t)mt * (32 * TTW);
-    const int nt0 = (nb * 4 + q) * NTW;
-    f32x16 acc[NTW][TTW];
-    if constexpr (EPI == 2) {  // oh / ol carry the residual planes here
-        if constexpr (NTW == 3 && TTW == 2) {
-            wt_res_init_global(acc, q, bias + nb * 384, oh + nb * 384, ol + nb * 384, m0, T, smem + q * LNT_TILE);
-            __syncthreads();
-        } else {
-            static_assert(NTW == 1 && TTW == 1, "residual init: 3 x 2 or 1 x 1 wave tiles");
-            wt_res_init_direct(acc, nt0, bias, oh, ol, N, m0, T);
-        }
-    }
-    wt_kloop<NTW, TTW, D, EPI != 2>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);
-    if constexpr (STAGED) {
-        // [384 features x 32 tokens] per pass -> stage[token][feature] (16-B LDS writes), then 16-B chunks in flat
-        // order: every wave store instruction writes 1 KB of at most two output rows.  (Storing 16 B per lane with
-        // the lanes 4,608 B apart took as long as the whole K loop: 32k of 69k cycles per block by in-kernel stamps.)
-        float* const stage = reinterpret_cast<float*>(smem);
-        const int n0 = nb * 384;
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int fl = q * 96 + i * 32 + 8 * g + 4 * h;
-                    f32x4 b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (EPI == 0) b = *reinterpret_cast<const f32x4*>(bias + n0 + fl);
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = EPI == 2 ? acc[i][tt][4 * g + j] * WT_UNSCALE : fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                    *reinterpret_cast<f32x4*>(stage + r * LN_LD + fl) = v;
-                }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const int f = threadIdx.x + 256 * k, row = f / 96, c = f - row * 96;
-                const int64_t tok = m0 + tt * 32 + row;
-                if (tok < T)
-                    *reinterpret_cast<f32x4*>(out + tok * N + n0 + c * 4) = *reinterpret_cast<const f32x4*>(stage + row * LN_LD + c * 4);
-            }
-            if (tt == 0) __syncthreads();
-        }
-        ICREC_STAMP(0, 30);
-        return;
-    }
-
-#pragma unroll
-    for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int feat = (nt0 + i) * 32 + 8 * g + 4 * h;
-            f32x4 b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (EPI != 2) b = *reinterpret_cast<const f32x4*>(bias + feat);
-#pragma unroll
-            for (int tt = 0; tt < TTW; ++tt) {
-                const int64_t tok = m0 + tt * 32 + r;
-                if (tok < T) {
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = EPI == 2 ? acc[i][tt][4 * g + j] * WT_UNSCALE : fmaf(acc[i][tt][4 * g + j], WT_UNSCALE, b[j]);
-                    if (EPI == 1) {
-                        half4 hi, lo;
-                        half2w a, b, c, d;
-                        split_pair_prescaled(gelu16_wt(v[0]), gelu16_wt(v[1]), a, b);
-                        split_pair_prescaled(gelu16_wt(v[2]), gelu16_wt(v[3]), c, d);
-                        hi = half4{a[0], a[1], c[0], c[1]};
-                        lo = half4{b[0], b[1], d[0], d[1]};
-                        *reinterpret_cast<half4*>(oh + tok * N + feat) = hi;
-                        *reinterpret_cast<half4*>(ol + tok * N + feat) = lo;
-                    } else {
-                        *reinterpret_cast<f32x4*>(out + tok * N + feat) = v;
-                    }
-                }
-            }
-        }
-    ICREC_STAMP(0, 30);
-}
-
-// Attention-output projection + residual + LayerNorm in one kernel (large batches): block = 64 tokens x all 384
-// features, K = 384.
-// VAR (tools/ffn_bench.hip only; the product uses 0): 1 = accumulators start from zero (no residual rows in),
-// 2 = no LayerNorm / write-out (one dummy store per thread keeps the K loop alive)
-template <int D, int VAR = 0>
-__global__ __launch_bounds__(256, 2) void wt_linear_ln_kernel(const _Float16* __restrict__ Ah,
-                                                              const _Float16* __restrict__ Al, int T, int K,
-                                                              const _Float16* __restrict__ Wp,
-                                                              const float* __restrict__ bias,
-                                                              _Float16* __restrict__ xh, _Float16* __restrict__ xl,
-                                                              const float* __restrict__ gam,
-                                                              const float* __restrict__ bet, float eps) {
-    static_assert(XRing<2>::BYTES >= LNT_BYTES, "the slab ring doubles as the LayerNorm scratch");
-    __shared__ __attribute__((aligned(16))) char smem[XRing<2>::BYTES];
-    const int q = wave_uniform(threadIdx.x >> 6);
-    const int64_t m0 = (int64_t)blockIdx.x * 64;
-    f32x16 acc[3][2];
-    if (!(VAR & 1)) {
-        wt_res_init_global(acc, q, bias, xh, xl, m0, T, smem + LNT_RED + q * LNT_TILE);
-        __syncthreads();  // the private tiles become the slab ring
-    }
-    wt_kloop<3, 2, D, (VAR & 1) != 0>(acc, Wp, q * 3, K, Ah, Al, m0, T, smem);  // ends with a barrier: the slab ring is free
-    if (VAR & 2) {
-        float sdum = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sdum += acc[i][tt][e];
-        if (sdum == 123.456f) xh[m0 * 384 + threadIdx.x] = (_Float16)sdum;
-        return;
-    }
-    wt_ln_out(acc, true, q, xh, xl, m0, T, gam, bet, eps, smem, [] { __syncthreads(); }, threadIdx.x);
-    ICREC_STAMP(0, 30);
-}
-
-// ---------------------------------------------------------------- fused FFN (large batches)
-// x <- LN(W2 . gelu(W1 . x + b1) + b2 + x)   (tf:334-351: BertIntermediate, BertOutput) for a block of 64 tokens,
-// without the [T, 1536] intermediate ever leaving the CU.  The 1,536 intermediate features are walked in 12 chunks
-// of 128; per chunk
-//   P1  S^T[128 x 64 tok] = W1[chunk] . X^T          K = 384; wave q: intermediates q*32..+31 (2 token tiles)
-//   G   H = split(gelu(S * 2^-14 + b1))              registers -> 8-byte LDS writes (4 consecutive k of a token)
-//   P2  Y^T[384 x 64 tok] += W2[:, chunk] . H^T      K = 128; wave q: features q*96..+95 (3 x 2 tiles, 96 regs)
-// then the residual + LayerNorm epilogue.  Per output the MFMA chain is exactly wt_kloop's (k-steps ascending,
-// the same three products per step), so the result equals FFN-up -> FFN-down -> add_ln through wt_linear_kernel
-// bit for bit.
-constexpr int FFN_IC = 128;
-
-// Producer / consumer form: one 8-wave workgroup per CU owning ALL 160 KB of LDS:
-//   * the block's 64 x 384 activation planes stay resident in LDS (96 KB) for all 12 chunks — no restream, no
-//     slab barriers;
-//   * waves 0-3 (producers) run P1 + GELU for chunk c+1 and write H into one half of a double buffer (2 x 32 KB)
-//     while waves 4-7 (consumers) run P2 of chunk c from the other half: ONE workgroup barrier per chunk;
-//   * each SIMD hosts one producer and one consumer.  They issue the same number of MFMAs per chunk (144 each);
-//     the producer runs at raised priority, so it finishes P1 early and its GELU (VALU) overlaps the consumer's
-//     MFMAs;
-//   * specialisation frees registers for deep weight prefetch rings (W1: 8 k-steps, W2: 4 k-steps ahead).
-constexpr int FFN2_XPLANE = 64 * 768;                    // [64 tokens][384 k] halfs: 768-B rows, 3 sub-rows of 256 B
-constexpr int FFN2_X_BYTES = 2 * FFN2_XPLANE;            // hi, lo
-constexpr int FFN2_HPLANE = 64 * 256;                    // [64 tokens][128 k] halfs
-constexpr int FFN2_HBUF = 2 * FFN2_HPLANE;               // hi, lo
-constexpr int FFN2_LDS = FFN2_X_BYTES + 2 * FFN2_HBUF;   // 163,840 B = the whole LDS of a CU
-static_assert(FFN2_LDS == 160 * 1024, "fused FFN LDS budget");
-
-__device__ __forceinline__ void bar_lds() {  // LDS hand-off barrier that leaves global loads in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int VAR>
-__global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict__ xh, _Float16* __restrict__ xl,
-                                                            int T, int I,
-                                                            const _Float16* __restrict__ W1p,
-                                                            const float* __restrict__ b1,
-                                                            const _Float16* __restrict__ W2p,
-                                                            const float* __restrict__ b2,
-                                                            const float* __restrict__ gam,
-                                                            const float* __restrict__ bet, float eps) {
-    constexpr int KS1 = 24;
-    extern __shared__ __attribute__((aligned(16))) char smem2[];
-    char* const Xs = smem2;
-    char* const Hs = smem2 + FFN2_X_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), q = wave & 3, r = lane & 31, h = lane >> 5;
-    const bool producer = wave < 4;
-    const int64_t m0 = (int64_t)blockIdx.x * 64;
-    const int NC = I / FFN_IC, KS2 = I / 16;
-
-    ICREC_STAMP(0, 0);
-    ICREC_STAMP(4, 0);
-    // ---- the block's activation planes -> LDS, once (16-B chunk c of token row t at sub-row c >> 4, slot (c ^ t) & 15)
-    {
-        u32x4 vh[6], vl[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
-            int64_t g = m0 + row;
-            g = g < T ? g : (int64_t)T - 1;
-            vh[i] = *reinterpret_cast<const u32x4*>(xh + g * 384 + c * 8);
-            vl[i] = *reinterpret_cast<const u32x4*>(xl + g * 384 + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
-            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
-            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
-            *reinterpret_cast<u32x4*>(Xs + FFN2_XPLANE + pos) = vl[i];
-        }
-    }
-
-    const unsigned lo8 = lane * 8;
-    f32x16 Y[3][2];  // consumers only (dead in the producer branch)
-    if (producer) {
-        // LDS byte address of this lane's fragment of token tile tt at 16-B chunk ch = 2 ks + h:
-        //   tok*768 + (ch >> 4)*256 + (((ch & 15) ^ (tok & 15)) << 4),  (ch & 15) ^ t = 2 (ks & 7) ^ (h ^ t)
-        int xb[8][2];
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int tok = tt * 32 + r;
-                xb[m][tt] = tok * 768 + (((2 * m) ^ h ^ (tok & 15)) << 4);
-            }
-        half8 wh[8][1], wl[8][1];
-        {
-            const _Float16* const wp0[1] = {W1p + wt_frag_off(q, 0, KS1)};
-#pragma unroll
-            for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
-        }
-        __syncthreads();  // X resident
-        ICREC_STAMP(0, 1);
-        // Software pipeline: iteration c runs P1(c) with the GELU of chunk c-1 spread over its k-steps (one group
-        // of 4 intermediates x 1 token tile every third k-step), so the producer's VALU work sits between its own
-        // MFMAs and the consumers' instead of behind them.  H[c-1] is handed over at the end of iteration c.
-        f32x16 S[1][2], Sp[1][2];  // this chunk's accumulators, the previous chunk's (being GELU'd)
-        f32x4 bias[4], biasp[4];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Sp[0][tt][e] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) biasp[g] = bias[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // one pipeline iteration: P1(c) (MMA = true) with G(c - 1) spread over its 24 k-steps; the drain iteration
-        // (MMA = false) runs only the G slices
-        auto iteration = [&](int c, auto mma_tag) {
-            constexpr bool MMA = decltype(mma_tag)::value;
-            const _Float16* const wp1[1] = {W1p + wt_frag_off((MMA ? c : 0) * 4 + q, 0, KS1)};
-            const _Float16* const wpn[1] = {W1p + wt_frag_off((MMA && c + 1 < NC ? c + 1 : 0) * 4 + q, 0, KS1)};
-            if (MMA) {  // this chunk's biases, loaded BEFORE the k-loop: a load issued behind the weight ring would make
-                        // its consumer wait for the whole ring (vmcnt counts in order)
-                const float* bp = b1 + c * FFN_IC + q * 32 + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
-            char* const Hb = Hs + ((c + 1) & 1) * FFN2_HBUF;  // H[(c - 1) & 1]
-            half8 fh[2][2], fl[2][2];  // the next k-step's fragments are read under the current one's MFMAs
-            half4 ghi, glo;            // the GELU group being assembled
-            if (MMA) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb[0][tt]);
-                    fl[0][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + xb[0][tt]);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                if (MMA) {
-                    if (ks + 1 < KS1 && !(VAR & 8)) {
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            const int pos = xb[(ks + 1) & 7][tt] + ((ks + 1) >> 3) * 256;
-                            fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
-                            fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
-                        }
-                    }
-                    wt_mma<1, 2, (VAR & 64) != 0>(S, wh[ks & 7], wl[ks & 7], fh[(VAR & 8) ? 0 : (ks & 1)], fl[(VAR & 8) ? 0 : (ks & 1)]);
-                    if (!(VAR & 4) && !((VAR & 128) && (ks & 1))) {  // straight-line refill: this chunk's k-step ks+8, or the next chunk's ks+8-24
-                                                                    // (VAR 128, timing only: every second refill skipped = half the weight stream)
-                        if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
-                        else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
-                    }
-                }
-                if (ks % 3 != 2) {  // G of the PREVIOUS chunk, two elements per k-step (16 of the 24 k-steps carry a slice):
-                                    // bias + erf-GELU + split; a finished group of 4 consecutive k goes out as one
-                                    // 8-byte LDS write per plane
-                    constexpr int dummy_ = 0;
-                    (void)dummy_;
-                    const int u = ks - ks / 3;
-                    {
-                        const int n = 2 * u, gi = n >> 2, j = n & 3, g = gi >> 1, tt = gi & 1;  // elements j, j + 1 of group gi
-                        const float p0 = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
-                        const float p1 = fmaf(Sp[0][tt][4 * g + j + 1], WT_UNSCALE, biasp[g][j + 1]);
-                        half2w a, d;
-                        split_pair_prescaled((VAR & 1) ? p0 : gelu16_wt(p0), (VAR & 1) ? p1 : gelu16_wt(p1), a, d);
-                        ghi[j] = a[0];
-                        ghi[j + 1] = a[1];
-                        glo[j] = d[0];
-                        glo[j + 1] = d[1];
-                    }
-                    if (u & 1) {
-                        const int gi = u >> 1, g = gi >> 1, tt = gi & 1;
-                        const int tok = tt * 32 + r;
-                        const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
-                        *reinterpret_cast<half4*>(Hb + pos) = ghi;  // iteration 0 writes GELU(0) into a buffer nobody reads yet
-                        *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = glo;
-                    }
-                    if (MMA && !(VAR & 32)) {  // the next step's LDS reads first; then one MFMA and a dozen of the slice's VALU
-                                               // instructions, six times
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                        for (int m = 0; m < 6; ++m) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch (and the GELU slice) to its k-step
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) Sp[0][tt] = S[0][tt];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) biasp[g] = bias[g];
-        };
-        for (int c = 0; c < NC; ++c) {
-            iteration(c, std::true_type{});
-            ICREC_STAMP(0, 2 + 2 * c);
-            if (c > 0) bar_lds();  // B(c): H[c - 1] is complete; the consumers have left H[c & 1]
-            ICREC_STAMP(0, 3 + 2 * c);
-        }
-        iteration(NC, std::false_type{});
-        bar_lds();  // B(NC): H[NC - 1]
-        ICREC_STAMP(0, 26);
-    } else {
-        const _Float16* w2p[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2);
-        int hb[2];  // tok*256 + ((h ^ (tok & 15)) << 4); chunk 2 k2 + h lands at hb ^ (k2 << 5)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) hb[tt] = (tt * 32 + r) * 256 + ((h ^ (r & 15)) << 4);
-        half8 wh[4][3], wl[4][3];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
-        __syncthreads();  // X resident (matches the producers' first barrier)
-        ICREC_STAMP(4, 1);
-        // Y starts from the residual + bias: the block's own planes, already in LDS (wt_res_init_*: same value)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = q * 12 + i * 4 + g;  // 16-B chunk of the token row holding features q*96 + i*32 + 8g .. +7
-                const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + q * 96 + i * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int tok = tt * 32 + r;
-                    const int pos = tok * 768 + (((c & ~15) | ((c ^ tok) & 15)) << 4) + 8 * h;
-                    const half4 a = *reinterpret_cast<const half4*>(Xs + pos);
-                    const half4 d = *reinterpret_cast<const half4*>(Xs + FFN2_XPLANE + pos);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Y[i][tt][4 * g + j] = res_init_val(a[j], d[j], b[j]);
-                }
-            }
-        bar_lds();        // B1: H[0] is ready
-        for (int c = 0; c < NC; ++c) {
-            ICREC_STAMP(4, 2 + 2 * c);
-            const char* const Hb = Hs + (c & 1) * FFN2_HBUF;
-            half8 fh[2][2], fl[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                fh[0][tt] = *reinterpret_cast<const half8*>(Hb + hb[tt]);
-                fl[0][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + hb[tt]);
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                if (k2 + 1 < 8 && !(VAR & 8)) {
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int pos = hb[tt] ^ ((k2 + 1) << 5);
-                        fh[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + pos);
-                        fl[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + pos);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // issue the next step's LDS reads before this step's 18 MFMAs
-                }
-                wt_mma<3, 2, (VAR & 64) != 0>(Y, wh[k2 & 3], wl[k2 & 3], fh[(VAR & 8) ? 0 : (k2 & 1)], fl[(VAR & 8) ? 0 : (k2 & 1)]);
-                if (!(VAR & 4) && !((VAR & 128) && (k2 & 1))) {
-                    int nk = c * 8 + k2 + 4;
-                    nk = nk < KS2 ? nk : KS2 - 1;  // past the end: re-read the last fragment (never consumed)
-                    w_load<3>(wh[k2 & 3], wl[k2 & 3], w2p, nk, lo8);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
-            }
-            ICREC_STAMP(4, 3 + 2 * c);
-            if (c + 1 < NC) bar_lds();  // B(c+2): done with H[c & 1]; H[(c + 1) & 1] is ready
-        }
-    }
-    ICREC_STAMP(0, 27);
-    ICREC_STAMP(4, 27);
-    // ---- LayerNorm on the consumers' accumulators (the producers only join the two barriers)
-    __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm scratch
-    wt_ln_out(Y, !producer, q, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, threadIdx.x);
-    ICREC_STAMP(0, 30);
-    ICREC_STAMP(4, 30);
-}
-
-// Persistent form of the same computation: one workgroup per CU walks blocks j = blockIdx.x, + gridDim.x, ... and the
-// block boundary is software-pipelined away.  Time is cut into epochs (one workgroup barrier each); in epoch (j, k)
-//   producers   k = 0: P1(0)   k = 1..11: P1(k) + G(k-1)   k = 12 ("drain"): G(11), and block j+1's planes -> LDS
-//   consumers   k = 0: P2(11) of block j-1   k = 1: LayerNorm + write-out of block j-1, then Y0 of block j
-//               k = 2..12: P2(k-2)
-// so the LayerNorm epilogue of a block runs in the slot where the consumers would wait for the first H chunk of the
-// next one, under the producers' MFMAs; its scratch is the H buffer that is idle in that epoch (H[1]: P2(11) has
-// consumed it, G(1) is written an epoch later), its two internal barriers are matched by two extra barriers inside
-// the producers' iteration 1.  The next block's activation planes travel global -> registers -> LDS inside the
-// drain epoch (the producers' MFMA-free epoch: weight ring, S and the fragment registers are idle), into the X
-// region that P1(11) has just left.  Arithmetic and order per output are those of ffn_fused2_kernel.
-__global__ __launch_bounds__(512, 2) void ffn_fused3_kernel(_Float16* __restrict__ xh, _Float16* __restrict__ xl,
-                                                            int T, int I, const _Float16* __restrict__ W1p,
-                                                            const float* __restrict__ b1,
-                                                            const _Float16* __restrict__ W2p,
-                                                            const float* __restrict__ b2,
-                                                            const float* __restrict__ gam,
-                                                            const float* __restrict__ bet, float eps) {
-    constexpr int KS1 = 24;
-    extern __shared__ __attribute__((aligned(16))) char smem3[];
-    char* const Xs = smem3;
-    char* const Hs = smem3 + FFN2_X_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), q = wave & 3, r = lane & 31, h = lane >> 5;
-    const bool producer = wave < 4;
-    const int G = gridDim.x, nblk = (T + 63) / 64;
-    const int J = (nblk - (int)blockIdx.x + G - 1) / G;  // blocks of this workgroup (host: gridDim.x <= nblk)
-    const int NC = I / FFN_IC, KS2 = I / 16;
-    auto block_m0 = [&](int j) { return (int64_t)(j * G + (int)blockIdx.x) * 64; };
-
-    // ---- stagger: the workgroups of a launch would otherwise walk their blocks in lockstep, and every block boundary
-    // (64 x 768 B of planes in, the same out) would hit HBM from all CUs in the same few microseconds.  Eight phases,
-    // ~1.5k cycles apart (about one epoch in total: the weight chunks the CUs of an XCD share stay the same ones).
-    for (int ph = ((int)blockIdx.x >> 3) & 7; ph > 0; --ph) __builtin_amdgcn_s_sleep(23);
-    // ---- the first block's activation planes -> LDS (16-B chunk c of token row t at sub-row c >> 4, slot (c ^ t) & 15)
-    {
-        const int64_t m0 = block_m0(0);
-        u32x4 vh[6], vl[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
-            int64_t g = m0 + row;
-            g = g < T ? g : (int64_t)T - 1;
-            vh[i] = *reinterpret_cast<const u32x4*>(xh + g * 384 + c * 8);
-            vl[i] = *reinterpret_cast<const u32x4*>(xl + g * 384 + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
-            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
-            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
-            *reinterpret_cast<u32x4*>(Xs + FFN2_XPLANE + pos) = vl[i];
-        }
-    }
-
-    const unsigned lo8 = lane * 8;
-    if (producer) {
-        int xb[8][2];
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int tok = tt * 32 + r;
-                xb[m][tt] = tok * 768 + (((2 * m) ^ h ^ (tok & 15)) << 4);
-            }
-        half8 wh[8][1], wl[8][1];
-        {
-            const _Float16* const wp0[1] = {W1p + wt_frag_off(q, 0, KS1)};
-#pragma unroll
-            for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
-        }
-        __syncthreads();  // X(0) resident
-        f32x16 S[1][2], Sp[1][2];
-        f32x4 bias[4], biasp[4];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Sp[0][tt][e] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) biasp[g] = bias[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        // one epoch of the producers: P1(c) if MMA, the GELU of the previous chunk spread over the k-steps if GEL;
-        // sync2: join the two internal barriers of the consumers' LayerNorm; the drain (!MMA) also moves the next
-        // block's planes (rows m0n ..) into LDS when there is one
-        // W1j / b1j: the weight and bias pointers, re-defined (opaquely) once per block - the same addresses are read
-        // for every block, and as loop-invariant loads the compiler would hoist a whole iteration's weight stream
-        // out of the block loop and spill it
-        const _Float16* W1j = W1p;
-        const float* b1j = b1;
-        auto iteration = [&](int c, auto mma_tag, auto gel_tag, bool sync2, int64_t m0n, bool has_next) {
-            constexpr bool MMA = decltype(mma_tag)::value, GEL = decltype(gel_tag)::value;
-            const _Float16* const wp1[1] = {W1j + wt_frag_off((MMA ? c : 0) * 4 + q, 0, KS1)};
-            const _Float16* const wpn[1] = {W1j + wt_frag_off((MMA && c + 1 < NC ? c + 1 : 0) * 4 + q, 0, KS1)};
-            if (MMA) {  // biases before the k-loop: a load issued behind the weight ring would wait for the whole ring
-                const float* bp = b1j + c * FFN_IC + q * 32 + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bp + 8 * g);
-            }
-            // drain: the next block's planes in four quarters of 6 chunks per producer thread (hi rows 0-31, hi rows 32-63,
-            // lo likewise), each requested 6 k-steps before it is written to LDS
-            u32x4 xv[6];
-            int tids = tid;  // opaque copy: keeps the drain's address arithmetic inside the drain (not hoisted across the block loop)
-            if (!MMA) asm volatile("" : "+v"(tids));
-            auto x_next_load = [&](int quarter) {
-                const _Float16* plane = quarter < 2 ? xh : xl;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int id = tids + 256 * (i + 6 * (quarter & 1)), row = id / 48, cc = id - row * 48;
-                    int64_t g = m0n + row;
-                    g = g < T ? g : (int64_t)T - 1;
-                    xv[i] = *reinterpret_cast<const u32x4*>(plane + g * 384 + cc * 8);
-                }
-            };
-            auto x_next_store = [&](int quarter) {
-                char* dst = Xs + (quarter < 2 ? 0 : FFN2_XPLANE);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int id = tids + 256 * (i + 6 * (quarter & 1)), row = id / 48, cc = id - row * 48;
-                    *reinterpret_cast<u32x4*>(dst + row * 768 + (((cc & ~15) | ((cc ^ row) & 15)) << 4)) = xv[i];
-                }
-            };
-            if (!MMA && has_next) x_next_load(0);
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
-            char* const Hb = Hs + ((c + 1) & 1) * FFN2_HBUF;  // H[(c - 1) & 1]
-            half8 fh[2][2], fl[2][2];
-            half4 ghi, glo;
-            if (MMA) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb[0][tt]);
-                    fl[0][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + xb[0][tt]);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                if (MMA && GEL && (ks == 8 || ks == 16)) {
-                    if (sync2) bar_lds();
-                }
-                if (MMA) {
-                    if (ks + 1 < KS1) {
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            const int pos = xb[(ks + 1) & 7][tt] + ((ks + 1) >> 3) * 256;
-                            fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
-                            fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
-                        }
-                    }
-                    wt_mma<1, 2>(S, wh[ks & 7], wl[ks & 7], fh[ks & 1], fl[ks & 1]);
-                    if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
-                    else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
-                }
-                if (GEL && ks % 3 != 2) {
-                    const int u = ks - ks / 3;
-                    {
-                        const int n = 2 * u, gi = n >> 2, j = n & 3, g = gi >> 1, tt = gi & 1;
-                        const float p0 = fmaf(Sp[0][tt][4 * g + j], WT_UNSCALE, biasp[g][j]);
-                        const float p1 = fmaf(Sp[0][tt][4 * g + j + 1], WT_UNSCALE, biasp[g][j + 1]);
-                        half2w a, d;
-                        split_pair_prescaled(gelu16_wt(p0), gelu16_wt(p1), a, d);
-                        ghi[j] = a[0];
-                        ghi[j + 1] = a[1];
-                        glo[j] = d[0];
-                        glo[j + 1] = d[1];
-                    }
-                    if (u & 1) {
-                        const int gi = u >> 1, g = gi >> 1, tt = gi & 1;
-                        const int tok = tt * 32 + r;
-                        const int pos = tok * 256 + (((4 * q + g) ^ (tok & 15)) << 4) + 8 * h;
-                        *reinterpret_cast<half4*>(Hb + pos) = ghi;
-                        *reinterpret_cast<half4*>(Hb + FFN2_HPLANE + pos) = glo;
-                    }
-                    if (MMA) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                        for (int m = 0; m < 6; ++m) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                        }
-                    }
-                }
-                if (!MMA && (ks == 5 || ks == 11 || ks == 17) && has_next) {
-                    x_next_store(ks / 6);
-                    x_next_load(ks / 6 + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!MMA && has_next) x_next_store(3);
-            if (MMA) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) Sp[0][tt] = S[0][tt];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) biasp[g] = bias[g];
-            }
-        };
-        for (int j = 0; j < J; ++j) {
-            {   // an opaque zero OFFSET (not an opaque pointer: that would turn the loads into flat_load, which count
-                // against lgkmcnt as well and serialise with the LDS fragment reads)
-                int zero = 0;
-                asm volatile("" : "+s"(zero));
-                W1j = W1p + zero;
-                b1j = b1 + zero;
-            }
-            if (j == 1) ICREC_STAMP(0, 0);
-            iteration(0, std::true_type{}, std::false_type{}, false, 0, false);
-            if (j == 1) ICREC_STAMP(0, 1);
-            bar_lds();
-            if (j == 1) ICREC_STAMP(0, 2);
-            for (int c = 1; c < NC; ++c) {
-                iteration(c, std::true_type{}, std::true_type{}, c == 1 && j > 0, 0, false);
-                if (j == 1) ICREC_STAMP(0, 1 + 2 * c);
-                bar_lds();
-                if (j == 1) ICREC_STAMP(0, 2 + 2 * c);
-            }
-            iteration(NC, std::false_type{}, std::true_type{}, false, block_m0(j + 1), j + 1 < J);
-            if (j == 1) ICREC_STAMP(0, 25);
-            bar_lds();
-            if (j == 1) ICREC_STAMP(0, 26);
-        }
-        bar_lds();  // epoch (J, 0): the consumers' last P2
-        bar_lds();  // the two barriers inside the last LayerNorm
-        bar_lds();
-    } else {
-        f32x16 Y[3][2];
-        const _Float16* w2p[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) w2p[i] = W2p + wt_frag_off(q * 3 + i, 0, KS2);
-        int hb[2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) hb[tt] = (tt * 32 + r) * 256 + ((h ^ (r & 15)) << 4);
-        half8 wh[4][3], wl[4][3];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
-        __syncthreads();  // X(0) resident (matches the producers' first barrier)
-        // LAST (chunk NC-1): no prefetch past the end - the ring is dead across the LayerNorm (which needs the
-        // registers) and is refilled for the next block right after it
-        auto P2 = [&](int c, auto last_tag) {
-            constexpr bool LAST = decltype(last_tag)::value;
-            const char* const Hb = Hs + (c & 1) * FFN2_HBUF;
-            half8 fh[2][2], fl[2][2];
-            int hbc[2] = {hb[0], hb[1]};  // opaque per chunk: the 14 derived fragment addresses are recomputed here (one
-                                          // v_xor each) instead of living in registers across the whole block loop
-            asm volatile("" : "+v"(hbc[0]), "+v"(hbc[1]));
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                fh[0][tt] = *reinterpret_cast<const half8*>(Hb + hbc[tt]);
-                fl[0][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + hbc[tt]);
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                if (k2 + 1 < 8) {
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int pos = hbc[tt] ^ ((k2 + 1) << 5);
-                        fh[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + pos);
-                        fl[(k2 + 1) & 1][tt] = *reinterpret_cast<const half8*>(Hb + FFN2_HPLANE + pos);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                wt_mma<3, 2>(Y, wh[k2 & 3], wl[k2 & 3], fh[k2 & 1], fl[k2 & 1]);
-                if (!LAST || k2 < 4) w_load<3>(wh[k2 & 3], wl[k2 & 3], w2p, c * 8 + k2 + 4, lo8);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        const float *b2j = b2, *gamj = gam, *betj = bet;
-        for (int j = 0; j <= J; ++j) {
-            {   // per-block opaque re-definition of the weight / parameter pointers (see the producers)
-                int zero = 0;
-                asm volatile("" : "+s"(zero));
-                b2j = b2 + zero;
-                gamj = gam + zero;
-                betj = bet + zero;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) w2p[i] = W2p + zero + wt_frag_off(q * 3 + i, 0, KS2);
-            }
-            if (j == 1) ICREC_STAMP(4, 0);
-            // requested now, used after the LayerNorm write-out: a load issued behind those stores would wait for them
-            const f32x4 parv = wt_ln_par_load(gamj, betj, tid - 256);
-            const f32x4 biasv = *reinterpret_cast<const f32x4*>(b2j + q * 96 + 4 * (lane < 24 ? lane : 0));
-            if (j > 0) P2(NC - 1, std::true_type{});
-            if (j == 1) ICREC_STAMP(4, 1);
-            bar_lds();  // end of epoch (j, 0)
-            if (j == 1) ICREC_STAMP(4, 2);
-            int salt = 0;  // see wt_ln_out
-            asm volatile("" : "+v"(salt));
-            if (j > 0)
-                wt_ln_out(Y, true, q, xh, xl, block_m0(j - 1), T, gamj, betj, eps, Hs + FFN2_HBUF, [] { bar_lds(); }, tid - 256, salt, &parv);
-            if (j == J) break;
-            if (j > 0) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) w_load<3>(wh[d], wl[d], w2p, d, lo8);
-            }
-            // Y starts from the residual + bias: the block's own planes, already in LDS (wt_res_init_*: same value); the
-            // wave's 96 bias values through its own (now idle) LayerNorm tile
-            float* const bq = reinterpret_cast<float*>(Hs + FFN2_HBUF + LNT_RED + q * LNT_TILE);
-            if (lane < 24) *reinterpret_cast<f32x4*>(bq + 4 * lane) = biasv;
-            lds_order();
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = q * 12 + i * 4 + g;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bq + i * 32 + 8 * g + 4 * h + salt);
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int tok = tt * 32 + r + salt;
-                        const int pos = tok * 768 + (((c & ~15) | ((c ^ tok) & 15)) << 4) + 8 * h;
-                        const half4 a = *reinterpret_cast<const half4*>(Xs + pos);
-                        const half4 d = *reinterpret_cast<const half4*>(Xs + FFN2_XPLANE + pos);
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) Y[i][tt][4 * g + jj] = res_init_val(a[jj], d[jj], b[jj]);
-                    }
-                }
-            if (j == 1) ICREC_STAMP(4, 3);
-            bar_lds();  // end of epoch (j, 1)
-            if (j == 1) ICREC_STAMP(4, 4);
-            for (int c = 0; c + 1 < NC; ++c) {
-                P2(c, std::false_type{});
-                if (j == 1) ICREC_STAMP(4, 5 + 2 * c);
-                bar_lds();
-                if (j == 1) ICREC_STAMP(4, 6 + 2 * c);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- QKV projection, activation-resident form (large batches)
-// out[T, N] = X . W^T + bias for a block of 64 tokens and ALL N = 1,152 features in one 8-wave workgroup, built like
-// the producer half of ffn_fused2_kernel: the block's 64 x 384 activation planes are loaded into LDS ONCE (96 KB; the
-// slab-ring form restreams them per 384-feature workgroup and pays a prologue, five slab barriers and an epilogue
-// barrier pair per 64 x 384 outputs), every wave walks whole feature tiles - wave w: tiles w, w + 8, ... (a SIMD
-// hosts waves s and s + 4 = 9 of the 36 tiles) - with K = 384 as 24 straight-line k-steps, the weight ring 8 k-steps
-// deep and running across tile boundaries, no workgroup barrier after the first.  Results leave through a private
-// per-wave LDS tile ([32 tokens][32 features] fp32, 144-B rows) as 16-B chunks: 128 B per token row per store.
-// Per output the MFMA chain is wt_kloop's: the same bits as wt_linear_kernel<3, 2, 2, 0>.
-constexpr int QKVR_STG_LD = 36;                                  // floats per staged row (+16 B)
-constexpr int QKVR_STG_BYTES = 32 * QKVR_STG_LD * 4;             // 4,608 B per wave
-constexpr int QKVR_LDS = FFN2_X_BYTES + 8 * QKVR_STG_BYTES;      // 135,168 B
-
-__global__ __launch_bounds__(512, 2) void qkv_resident_kernel(const _Float16* __restrict__ xh,
-                                                              const _Float16* __restrict__ xl, int T,
-                                                              const _Float16* __restrict__ Wp,
-                                                              const float* __restrict__ bias,
-                                                              float* __restrict__ out, int N) {
-    constexpr int KS1 = 24;
-    extern __shared__ __attribute__((aligned(16))) char smem2[];
-    char* const Xs = smem2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), r = lane & 31, h = lane >> 5;
-    float* const stg = reinterpret_cast<float*>(smem2 + FFN2_X_BYTES + wave * QKVR_STG_BYTES);
-    const int64_t m0 = (int64_t)blockIdx.x * 64;
-    const int NT = N / 32;
-    // ---- the block's activation planes -> LDS, once (layout of ffn_fused2_kernel)
-    {
-        u32x4 vh[6], vl[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
-            int64_t g = m0 + row;
-            g = g < T ? g : (int64_t)T - 1;
-            vh[i] = *reinterpret_cast<const u32x4*>(xh + g * 384 + c * 8);
-            vl[i] = *reinterpret_cast<const u32x4*>(xl + g * 384 + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 512 * i, row = id / 48, c = id - row * 48;
-            const int pos = row * 768 + (((c & ~15) | ((c ^ row) & 15)) << 4);
-            *reinterpret_cast<u32x4*>(Xs + pos) = vh[i];
-            *reinterpret_cast<u32x4*>(Xs + FFN2_XPLANE + pos) = vl[i];
-        }
-    }
-    const unsigned lo8 = lane * 8;
-    int xb[8][2];
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int tok = tt * 32 + r;
-            xb[m][tt] = tok * 768 + (((2 * m) ^ h ^ (tok & 15)) << 4);
-        }
-    half8 wh[8][1], wl[8][1];
-    {
-        const _Float16* const wp0[1] = {Wp + wt_frag_off(wave, 0, KS1)};
-#pragma unroll
-        for (int d = 0; d < 8; ++d) w_load<1>(wh[d], wl[d], wp0, d, lo8);
-    }
-    __syncthreads();  // X resident
-    // (Spreading a tile's write-out over the next tile's k-steps - one store per k-step instead of a burst of eight -
-    // was measured at the same speed with 256 instead of 190 VGPRs; running without any store is 72 us per launch
-    // faster: the 604 MB of fp32 QKV rows per launch are what the rest of the time buys.)
-    for (int nt = wave; nt < NT; nt += 8) {
-        const int nn = nt + 8 < NT ? nt + 8 : nt;  // past the last tile: re-read this one's fragments (never consumed)
-        const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
-        const _Float16* const wpn[1] = {Wp + wt_frag_off(nn, 0, KS1)};
-        f32x4 bv[4];  // loaded BEFORE the k-loop (vmcnt counts in order: behind the ring it would wait for the whole ring)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + 8 * g + 4 * h);
-        f32x16 S[1][2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
-        half8 fh[2][2], fl[2][2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb[0][tt]);
-            fl[0][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + xb[0][tt]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-            if (ks + 1 < KS1) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int pos = xb[(ks + 1) & 7][tt] + ((ks + 1) >> 3) * 256;
-                    fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
-                    fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + FFN2_XPLANE + pos);
-                }
-            }
-            wt_mma<1, 2>(S, wh[ks & 7], wl[ks & 7], fh[ks & 1], fl[ks & 1]);
-            if (ks + 8 < KS1) w_load<1>(wh[ks & 7], wl[ks & 7], wp1, ks + 8, lo8);
-            else w_load<1>(wh[ks & 7], wl[ks & 7], wpn, ks + 8 - KS1, lo8);
-            __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
-        }
-        // ---- this tile out: [32 tokens][32 features] per pass through the wave's private LDS tile
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaf(S[0][tt][4 * g + j], WT_UNSCALE, bv[g][j]);
-                *reinterpret_cast<f32x4*>(stg + r * QKVR_STG_LD + 8 * g + 4 * h) = v;
-            }
-            lds_order();
-            f32x4 o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int f = lane + 64 * k;
-                o[k] = *reinterpret_cast<const f32x4*>(stg + (f >> 3) * QKVR_STG_LD + (f & 7) * 4);
-            }
-            lds_order();  // the tile is free for the next pass before the stores are issued
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int f = lane + 64 * k;
-                const int64_t tok = m0 + tt * 32 + (f >> 3);
-                if (tok < T) *reinterpret_cast<f32x4*>(out + tok * N + nt * 32 + (f & 7) * 4) = o[k];
-            }
-        }
-    }
-}
-
-// W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int N, int K,
-                                                           _Float16* __restrict__ out) {
-    const int KS = K / 16;
-    const size_t n = (size_t)(N / 32) * KS * 64;
-    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (size_t)gridDim.x * 256) {
-        const size_t fr = id >> 6;
-        const int lane = (int)(id & 63), r = lane & 31, h = lane >> 5;
-        const int nt = (int)(fr / KS), ks = (int)(fr % KS);
-        const float* src = w + (size_t)(nt * 32 + r) * K + ks * 16 + 8 * h;
-        half8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 a, b;
-            split_scaled(src[j], WT_SW, a, b);
-            hi[j] = a;
-            lo[j] = b;
-        }
-        *reinterpret_cast<half8*>(out + fr * (2 * WT_FRAG) + lane * 8) = hi;
-        *reinterpret_cast<half8*>(out + fr * (2 * WT_FRAG) + WT_FRAG + lane * 8) = lo;
     }
 }
 
@@ -1930,6 +698,12 @@ struct Encoder {
     _Float16* planes = nullptr; // packed weight fragments (F16X3)
     float *word, *pos, *type, *eg, *eb;
     LayerW layers[64];
+    // A/B switches, read from the environment ONCE, at icrec_encoder_create (never on the hot path; a test that wants
+    // the other form creates a second encoder under the other setting):
+    //   ICREC_FUSE=0         the UNFUSED reference chain for batches: slab-ring QKV, attention-out GEMM + LayerNorm,
+    //                        FFN-up, FFN-down + LayerNorm as separate launches in natural sequence order (same bits)
+    //   ICREC_SIDE_STREAM=0  every kernel on the caller's stream (no side stream for the batch remainder / short buckets)
+    bool fuse = true, side_stream = true;
     // Side stream + events of one caller stream: the short remainder of a large batch (batch_split) and the shorter
     // attention buckets run beside the batch kernels of the same layer instead of behind them.  One set per caller
     // stream (created on first use, kept for the encoder's life), so that concurrent icrec_encode calls on different
@@ -2004,11 +778,11 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
                              const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
     if (T <= X3_SMALL_M) {
         const int nbn = N / 128;
-        hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
+        hipLaunchKernelGGL((wt_linear_kernel<1, 1, 2, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
                            Wp, N, bias, out, oh, ol, nbn);
     } else {
         const int nbn = N / 384;
-        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, EPI>), dim3(((T + 63) / 64) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
+        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 1, EPI>), dim3(((T + 63) / 64) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
                            Wp, N, bias, out, oh, ol, nbn);
     }
 }
@@ -2066,6 +840,12 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
     e->cfg = *cfg;
     e->device = device;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        const char* fuse_env = getenv("ICREC_FUSE");
+        const char* side_env = getenv("ICREC_SIDE_STREAM");
+        e->fuse = !(fuse_env && fuse_env[0] == '0');
+        e->side_stream = !(side_env && side_env[0] == '0');
+    }
     const size_t H = cfg->hidden, I = cfg->intermediate;
     const size_t mat_per_layer = 3 * H * H + H * H + I * H + H * I;
     const bool x3 = cfg->gemm_mode == ICREC_GEMM_F16X3;
@@ -2195,18 +975,13 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     // whole rounds of the fused FFN kernel (one 64-token workgroup per CU) + a short remainder, see the layer loop
     int T_main, T_tail;
     batch_split(e, T, &T_main, &T_tail);
-    const char* fuse_env = getenv("ICREC_FUSE");  // ICREC_FUSE=0: A/B switch to the unfused kernels (read per call: tests flip it)
-    const bool fuse = !(fuse_env && fuse_env[0] == '0');
-    const char* side_env = getenv("ICREC_SIDE_STREAM");  // ICREC_SIDE_STREAM=0: the remainder's kernels stay on the caller's stream (A/B)
-    const bool side_stream = !(side_env && side_env[0] == '0');
-    const bool persist = fuse_env && fuse_env[0] == '3';
-    const char* qr_env = getenv("ICREC_QKV_RESIDENT");  // ICREC_QKV_RESIDENT=0: A/B switch to the slab-ring QKV kernel (same bits)
-    const bool qkv_res = !(qr_env && qr_env[0] == '0') && H == 384;
+    const bool fuse = e->fuse, side_stream = e->side_stream;
+    const bool qkv_res = fuse && H == 384;
     const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
     Encoder::Side* sd = nullptr;
     if (x3 && side_stream && (T_tail || split_att))
         if (int rc_ = side_for(e, st, &sd)) return rc_;
-    const bool use_side = sd != nullptr;  // ICREC_FUSE=3: the persistent, block-pipelined fused FFN kernel (same bits, same speed: DESIGN.md 4.2)
+    const bool use_side = sd != nullptr;
     // f16 hi/lo planes (F16X3): x, ctx and h; ctx/h planes alias the fp32 regions they replace
     _Float16* xh = reinterpret_cast<_Float16*>(base + w.xs);
     _Float16* xl = xh + (size_t)T * H;
@@ -2216,15 +991,13 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     _Float16* hl = hh + (size_t)T * I;
 
     // f16x3 mode: the fp32 x region of the workspace is unused (the residual stream is its two planes): it carries the
-    // attention dispatch order of batches (ICREC_ATT_ORDER=0: workgroup b serves sequence b / heads, A/B)
+    // attention dispatch order of batches (the unfused reference chain keeps the natural order: workgroup b serves
+    // sequence b / heads)
     const int32_t* order = nullptr;
-    {
-        const char* ao = getenv("ICREC_ATT_ORDER");
-        if (x3 && n_seqs >= 64 && !(ao && ao[0] == '0')) {
-            int32_t* ord = reinterpret_cast<int32_t*>(x);
-            hipLaunchKernelGGL(seq_order_kernel, dim3(1), dim3(1024), 0, st, cu_dev, n_seqs, ord);
-            order = ord;
-        }
+    if (x3 && n_seqs >= 64 && fuse) {
+        int32_t* ord = reinterpret_cast<int32_t*>(x);
+        hipLaunchKernelGGL(seq_order_kernel, dim3(1), dim3(1024), 0, st, cu_dev, n_seqs, ord);
+        order = ord;
     }
     if (x3)
         hipLaunchKernelGGL((embed_ln_kernel<HID, true>), dim3(rows_grid), dim3(256), 0, st, ids_dev, cu_dev, n_seqs, T,
@@ -2255,33 +1028,25 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 _Float16 *const xhr = xh + (size_t)r0 * H, *const xlr = xl + (size_t)r0 * H;
                 const _Float16 *const chr = ch + (size_t)r0 * H, *const clr = cl + (size_t)r0 * H;
                 if (Tn > X3_SMALL_M && fuse) {
-                    // attention-out + residual + LN, then the whole FFN block + residual + LN: two kernels per half layer
-                    hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((Tn + 63) / 64), dim3(256), 0, st, chr, clr, Tn, H,
-                                       L.Wo_p, L.bo, xhr, xlr, L.g1, L.b1n, c.ln_eps);
+                    // attention-out + residual + LN and the whole FFN block + residual + LN: ONE kernel per half layer
+                    // (x1 stays on chip between the two LayerNorm sites)
                     ScopedTimer tm(T_FFN_UP, st);
                     const int nblk = (Tn + 63) / 64;
-                    if (persist) {
-                        auto kern = ffn_fused3_kernel;
-                        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
-                        hipLaunchKernelGGL(kern, dim3(nblk < e->n_cu ? nblk : e->n_cu), dim3(512), FFN2_LDS, st, xhr, xlr, Tn,
-                                           I, L.W1_p, L.b1, L.W2_p, L.b2, L.g2, L.b2n, c.ln_eps);
-                    } else {
-                        auto kern = ffn_fused2_kernel<0>;
-                        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
-                        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), FFN2_LDS, st, xhr, xlr, Tn, I, L.W1_p, L.b1, L.W2_p,
-                                           L.b2, L.g2, L.b2n, c.ln_eps);
-                    }
+                    auto kern = ffn_fused2_kernel<0, true>;
+                    if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
+                    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), FFN2_LDS, st, xhr, xlr, Tn, I, L.W1_p, L.b1, L.W2_p,
+                                       L.b2, L.g2, L.b2n, c.ln_eps, chr, clr, L.Wo_p, L.bo, L.g1, L.b1n);
                 } else {
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
                     launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes
-                    hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, Tn, L.g1, L.b1n,
+                    hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 15) / 16), dim3(256), 0, st, t1r, Tn, L.g1, L.b1n,
                                        c.ln_eps, xhr, xlr);
                     {
                         ScopedTimer tm(Tn > X3_SMALL_M ? T_FFN_UP : T_NSLOTS - 1, st);
                         launch_wt_linear<1>(xhr, xlr, Tn, H, L.W1_p, I, L.b1, nullptr, hhr, hlr, st);
                     }
                     launch_wt_linear<2>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, xhr, xlr, st);
-                    hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 31) / 32), dim3(256), 0, st, t1r, Tn, L.g2, L.b2n,
+                    hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 15) / 16), dim3(256), 0, st, t1r, Tn, L.g2, L.b2n,
                                        c.ln_eps, xhr, xlr);
                 }
                 return ICREC_OK;

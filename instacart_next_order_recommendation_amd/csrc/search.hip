@@ -157,6 +157,26 @@ __device__ __forceinline__ void merge_queue2(u64* list, const u64* queue, int qc
 // Grid: n_chunks * n_qtiles blocks (XCD-remapped).  Block (chunk, qtile) scores catalog row
 // tiles [chunk*tiles_per_chunk, ...) against query tile qtile and keeps, per query, the k best
 // (score, row) seen, then writes them (sorted, as keys) to partial[chunk][query][0..k).
+// ---- fragment helpers of the RESIDENT filter pass (PMODE 3).  This pass keeps the v_mfma_f32_32x32x16_f16 form of
+// the weights-direct engine (its selection code is written for the 32x32 accumulator map; the pass is ~3 % of a
+// recommend step): catalog rows packed as [32-row tile][16-deep k-step][plane] fragments of 1 KB, lane (h << 5 | r)
+// holding row r, k = 16 ks + 8 h .. +7.  (The encoder's linear layers use the 16x16x32 form, wt_gemm.h.)
+__device__ __forceinline__ size_t r32_frag_off(int nt, int ks, int KS) { return ((size_t)nt * KS + ks) * (2 * WT_FRAG); }
+__device__ __forceinline__ void r32_w_load(half8& wh, half8& wl, const _Float16* wp, int ks, unsigned lo8) {
+    const _Float16* p = wp + (size_t)ks * (2 * WT_FRAG);
+    wh = *reinterpret_cast<const half8*>(p + lo8);
+    wl = *reinterpret_cast<const half8*>(p + WT_FRAG + lo8);
+}
+__device__ __forceinline__ void r32_mma(f32x16 (&acc)[1][2], const half8& wh, const half8& wl, const half8 (&xh)[2],
+                                        const half8 (&xl)[2]) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[tt], acc[0][tt], 0, 0, 0);
+        acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[tt], acc[0][tt], 0, 0, 0);
+        acc[0][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[tt], acc[0][tt], 0, 0, 0);
+    }
+}
+
 // EMIT = true additionally stores every score to scores_out[q*N + row] (parity checks only).
 // PMODE 0: fp32 rows.  1: rows stored as bfloat16 (ICREC_ROWS_BF16), widened on their way into LDS.
 // 2: the FILTER pass of ICREC_ROWS_F32_FILTER — rows and queries as f16 hi/lo planes (P/P2, Qn/Q2), scores from
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     f32x16 acc[Cfg::TM][Cfg::TN];
 
     // ---- PMODE 3: query planes -> LDS (once), weight ring of the first round
-    half8 rwh[8][1], rwl[8][1];
+    half8 rwh[8], rwl[8];
     int xb0[2] = {0, 0};
     const unsigned lo8 = lane * 8;
     if constexpr (PMODE == 3) {
@@ -250,9 +270,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
             xb0[tt] = tok * 768 + (((lane >> 5) ^ (tok & 15)) << 4);
         }
         if (t_begin < t_end) {
-            const _Float16* const wp0[1] = {static_cast<const _Float16*>(P) + wt_frag_off(t_begin * 8 + wave, 0, RES_KS)};
+            const _Float16* const wp0 = static_cast<const _Float16*>(P) + r32_frag_off(t_begin * 8 + wave, 0, RES_KS);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) w_load<1>(rwh[d], rwl[d], wp0, d, lo8);
+            for (int d = 0; d < 8; ++d) r32_w_load(rwh[d], rwl[d], wp0, d, lo8);
         }
         __syncthreads();  // queries resident
     }
@@ -263,8 +283,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
             const char* const Xs = smem_raw;
             const int rt = tile * 8 + wave;
             const int rn = tile + 1 < t_end ? rt + 8 : rt;  // past the block's last round: re-read (never consumed)
-            const _Float16* const wp1[1] = {static_cast<const _Float16*>(P) + wt_frag_off(rt, 0, RES_KS)};
-            const _Float16* const wpn[1] = {static_cast<const _Float16*>(P) + wt_frag_off(rn, 0, RES_KS)};
+            const _Float16* const wp1 = static_cast<const _Float16*>(P) + r32_frag_off(rt, 0, RES_KS);
+            const _Float16* const wpn = static_cast<const _Float16*>(P) + r32_frag_off(rn, 0, RES_KS);
             f32x16 S[1][2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -286,9 +306,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
                         fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + pos);
                     }
                 }
-                wt_mma<1, 2>(S, rwh[ks & 7], rwl[ks & 7], fh[ks & 1], fl[ks & 1]);
-                if (ks + 8 < RES_KS) w_load<1>(rwh[ks & 7], rwl[ks & 7], wp1, ks + 8, lo8);
-                else w_load<1>(rwh[ks & 7], rwl[ks & 7], wpn, ks + 8 - RES_KS, lo8);
+                r32_mma(S, rwh[ks & 7], rwl[ks & 7], fh[ks & 1], fl[ks & 1]);
+                if (ks + 8 < RES_KS) r32_w_load(rwh[ks & 7], rwl[ks & 7], wp1, ks + 8, lo8);
+                else r32_w_load(rwh[ks & 7], rwl[ks & 7], wpn, ks + 8 - RES_KS, lo8);
                 __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
             }
 #pragma unroll

@@ -2,27 +2,39 @@
 //
 // Every linear layer of the encoder is out[T, N] = X[T, K] . W[N, K]^T with a STATIC weight matrix and M = T
 // tokens.  The engine computes the transposed tile  out^T = W . X^T  so that
-//   * the weight fragments are the A operand of v_mfma_f32_32x32x16_f16.  Each wave owns distinct output
-//     features, so no other wave of the workgroup needs its weight fragments: they are loaded straight from
-//     global memory (L2) into registers and never touch LDS.  Weights are pre-packed once at encoder creation
-//     in FRAGMENT ORDER — the 1 KB a wave needs for one (32-feature tile, 16-deep k-step, plane) is contiguous,
-//     lane l's 16 bytes at l * 16 — so every weight load is one fully coalesced global_load_dwordx4;
-//   * the token rows are the B operand: a [BM tokens x 64 k] slab of the activation planes is staged through
-//     LDS (XOR-swizzled 128-B rows, conflict-free ds_read_b128) and shared by the four waves;
+//   * the weight fragments are the A operand of the MFMA.  Each wave owns distinct output features, so no other
+//     wave of the workgroup needs its weight fragments: they are loaded straight from global memory (L2) into
+//     registers and never touch LDS.  Weights are pre-packed once at encoder creation in FRAGMENT ORDER — the 4 KB a
+//     wave needs for one (32-feature block, 32-deep k-step) are contiguous, lane l's 16 bytes of each of its four
+//     fragments at l * 16 — so every weight load is one fully coalesced global_load_dwordx4;
+//   * the token rows are the B operand: the activation planes are staged through LDS (XOR-swizzled rows,
+//     conflict-free ds_read_b128) and shared by the waves;
 //   * the accumulators come out with the TOKEN on the lane and 4 consecutive FEATURES in consecutive
-//     registers: epilogues store 16 B (fp32) or 8 B (f16 planes) per lane, a GELU'd tile can be handed to the
-//     next GEMM as 8-byte LDS writes, and LayerNorm statistics never need a cross-lane transpose.
+//     registers: epilogues store 16 B (fp32) or 8 B (f16 planes) per lane, a GELU'd tile is handed to the next GEMM
+//     as 8-byte LDS writes, and LayerNorm statistics need two shuffles and no transpose.
+//
+// MFMA shape: v_mfma_f32_16x16x32_f16 (round 3; rounds 1-2 used 32x32x16).  Same FLOPs per cycle, same operand and
+// accumulator bytes per FLOP - but under this engine's load the chip is power-limited, and it holds a higher clock
+// on the 16x16x32 form: on random operands a registers-only loop delivers 1,970 vs 1,710 TFLOP/s (1.95 vs 1.69 GHz,
+// tools/mfma_shape.hip, profiles/r03_mfma_shape_microbench.txt), and the fused FFN kernel issued in this shape ran
+// 1.33x faster before its data layout existed (tools/ffn_bench.hip VAR 64, profiles/r03_ffn_harness_shape_and_stream.txt).
+//   lane l = (g << 4 | c), c = l & 15, g = l >> 4
+//   A (16 rows x 32 k):  lane holds A[row c][k = 8g .. 8g+7]        B (32 k x 16 cols): lane holds B[k = 8g .. 8g+7][col c]
+//   D (16 x 16):         lane holds D[row 4g + reg][col c], reg = 0..3      (checked with integer data: tools/mfma16_probe.hip)
+// A 32-feature x 32-token BLOCK of out^T is 2 x 2 such tiles ([fi][ti], 16 accumulator registers as before): lane
+// (c, g) holds features fi*16 + 4g + reg of tokens ti*16 + c.
 //
 // Arithmetic (fp32-accurate on the f16 matrix cores): every fp32 operand is carried as two f16 planes
 //     hi = f16(x * S)        lo = f16(x * S - hi)                 S = 16 (activations), 1024 (weights)
 // and a product is   x*w*S_a*S_w ~= hi_w*hi_x + lo_w*hi_x + hi_w*lo_x   — three MFMAs into ONE fp32
-// accumulator, in that order, k-steps ascending; the result is scaled back by 2^-14 in the epilogue.  f16 x f16
+// accumulator, in that order, k-steps of 32 ascending; the result is scaled back by 2^-14 in the epilogue.  f16 x f16
 // products are exact in the fp32 accumulator; the dropped lo*lo term and the split residuals are <= 3 * 2^-22
 // relative per product.  The power-of-two scales keep `lo` out of the f16 subnormal range for every value that
 // matters (|x| >= 2^-7 / S: absolute error below 2^-25 / S otherwise) and are exact; |x| * S is clamped to the
 // f16 range (|activation| <= 4094, |weight| <= 63.9: far outside what LayerNorm-bounded BERT tensors reach).
-// One accumulator set instead of two (the previous round's hi/cross split) halves the accumulator registers,
-// which is what lets a wave own a 96-feature x 64-token output tile.
+// An output's value depends only on its own row of W and its own token's row of X (the matrix core's summation
+// order over the 32 k of a step is a function of k alone), so a token encodes to the same bits whichever kernel,
+// tile position or batch computed it — the bitwise tests between the small-batch, batch and fused forms rest on this.
 #pragma once
 #include "common.h"
 #include "gemm_x3.h"  // half8 / half4 / u32x4
@@ -55,13 +67,16 @@ __device__ __forceinline__ void split_pair_prescaled(float s0, float s1, half2w&
     hi = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(h0, h1));
     lo = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(s0 - h0, s1 - h1));
 }
-// four consecutive elements -> the 8-byte hi and lo pieces the epilogues store
-__device__ __forceinline__ void split_act4(const f32x4& v, half4& hi, half4& lo) {
+// four consecutive elements, already multiplied by the plane scale -> the 8-byte hi and lo pieces
+__device__ __forceinline__ void split4_prescaled(const f32x4& s, half4& hi, half4& lo) {
     half2w a, b, c, d;
-    split_pair_prescaled(v[0] * WT_SA, v[1] * WT_SA, a, b);
-    split_pair_prescaled(v[2] * WT_SA, v[3] * WT_SA, c, d);
+    split_pair_prescaled(s[0], s[1], a, b);
+    split_pair_prescaled(s[2], s[3], c, d);
     hi = half4{a[0], a[1], c[0], c[1]};
     lo = half4{b[0], b[1], d[0], d[1]};
+}
+__device__ __forceinline__ void split_act4(const f32x4& v, half4& hi, half4& lo) {
+    split4_prescaled(f32x4{v[0] * WT_SA, v[1] * WT_SA, v[2] * WT_SA, v[3] * WT_SA}, hi, lo);
 }
 __device__ __forceinline__ void split_act(float x, _Float16& hi, _Float16& lo) {
     half2w a, b;
@@ -71,15 +86,28 @@ __device__ __forceinline__ void split_act(float x, _Float16& hi, _Float16& lo) {
 }
 
 // ---------------------------------------------------------------- packed weights
-// W [N, K] fp32 row-major -> fragment order: fragment (nt, ks, plane) = 512 halfs at ((nt * K/16 + ks) * 2 + plane) * 512,
-// lane l = (h << 5 | r) holds W[nt*32 + r][ks*16 + 8h .. +7] (the A-operand map of v_mfma_f32_32x32x16_f16).
+// W [N, K] fp32 row-major -> fragment order.  Fragment = the 1 KB one wave feeds to one MFMA as its A operand: lane
+// l = (g << 4 | c) holds W[16-feature tile row c][k = ks*32 + 8g .. +7] of one plane.  The four fragments of a
+// (32-feature block nt, k-step ks) - [fi = 0, 1 feature halves][plane = hi, lo] - are contiguous: 2,048 halfs at
+// ((nt * K/32 + ks) * 4 + fi * 2 + plane) * 512.
 constexpr int WT_FRAG = 512;  // halfs per fragment (64 lanes x 8)
-__device__ __forceinline__ size_t wt_frag_off(int nt, int ks, int KS) { return ((size_t)nt * KS + ks) * (2 * WT_FRAG); }
+__device__ __forceinline__ size_t wt_frag_off(int nt, int ks, int KS) { return ((size_t)nt * KS + ks) * (4 * WT_FRAG); }
+
+struct WFrag { half8 h[2], l[2]; };   // weight fragments of one 32-feature block, one k-step: [fi] hi / lo
+struct XFrag { half8 h[2], l[2]; };   // activation fragments of one 32-token block, one k-step: [ti] hi / lo
+struct Acc32 { f32x4 t[2][2]; };      // a 32-feature x 32-token block of out^T: [fi][ti]
+
+__device__ __forceinline__ void acc_zero(Acc32& a) {
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) a.t[fi][ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
 
 // ---------------------------------------------------------------- activation slab ring (LDS)
-// A slab = BM = 32 * TTW token rows x 64 k of both planes; row = 128 B per plane, 16-B chunk c of row `row` is
-// stored at chunk c ^ ((row >> 1) & 7): the 16 lanes of a ds_read_b128 group land on 16 distinct 16-B slots
-// of the 256-B bank row.
+// A slab = BM = 32 * TTW token rows x 64 k of both planes; row = 128 B per plane, 16-B chunk ch of row `row` is
+// stored at chunk ch ^ ((row >> 1) & 7): the 16 lanes of every ds_read_b128 lane group of a fragment read (rows
+// c, chunks 4j + g) land on 16 distinct 16-B slots of the 256-B bank row.
 template <int TTW>
 struct XRing {
     static constexpr int BM = 32 * TTW;
@@ -116,57 +144,48 @@ __device__ __forceinline__ void x_store(const u32x4 (&xr)[2 * TTW], char* stage)
     }
 }
 
-// B fragment of token tile tt, k-step j (0..3) of the slab: lane (r, h) -> token tt*32 + r, k = 16 j + 8 h .. +7
-__device__ __forceinline__ half8 x_frag(const char* plane, int tt, int j, int r, int h) {
-    const int row = tt * 32 + r;
-    return *reinterpret_cast<const half8*>(plane + row * 128 + (((2 * j + h) ^ ((row >> 1) & 7)) << 4));
+// B fragments of token block tt, k-step j (0, 1) of the slab: lane (c, g) -> tokens tt*32 + ti*16 + c, k = 32 j + 8 g .. +7
+template <int TTW>
+__device__ __forceinline__ void x_frag(XFrag& x, const char* stage, int tt, int j, int c, int g) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int row = tt * 32 + ti * 16 + c;
+        const int pos = row * 128 + (((4 * j + g) ^ ((row >> 1) & 7)) << 4);
+        x.h[ti] = *reinterpret_cast<const half8*>(stage + pos);
+        x.l[ti] = *reinterpret_cast<const half8*>(stage + XRing<TTW>::PLANE_BYTES + pos);
+    }
 }
 
-// ---------------------------------------------------------------- one k-step of MFMAs
-// acc[i][tt] += W_i . X_tt^T over 16 k: (w_hi, x_hi), (w_lo, x_hi), (w_hi, x_lo) — the canonical order every
+// ---------------------------------------------------------------- one k-step of MFMAs for one 32-token block
+// acc[i] += W_i . X^T over 32 k: per 16x16 tile (w_hi, x_hi), (w_lo, x_hi), (w_hi, x_lo) — the canonical order every
 // kernel of the engine uses, so a token's result is independent of which kernel / tile shape computed it.
-// SHAPE16 (tools/ffn_bench.hip only, TIMING ONLY - the results are meaningless): every 32x32x16 MFMA is issued as
-// two v_mfma_f32_16x16x32_f16 on quarters of the same accumulator with the same operand registers: the FLOPs, the
-// matrix-pipe cycles and the operand traffic of a 16x16x32 port of the engine without its data layout.
-template <int NTW, int TTW, bool SHAPE16 = false>
-__device__ __forceinline__ void wt_mma(f32x16 (&acc)[NTW][TTW], const half8 (&wh)[NTW], const half8 (&wl)[NTW],
-                                       const half8 (&xh)[TTW], const half8 (&xl)[TTW]) {
+__device__ __forceinline__ void wt_mma_block(Acc32& a, const WFrag& w, const XFrag& x) {
 #pragma unroll
-    for (int i = 0; i < NTW; ++i)
+    for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-        for (int tt = 0; tt < TTW; ++tt) {
-            if constexpr (SHAPE16) {
-                f32x4 q[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = f32x4{acc[i][tt][4 * u], acc[i][tt][4 * u + 1], acc[i][tt][4 * u + 2], acc[i][tt][4 * u + 3]};
-                q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[tt], q[0], 0, 0, 0);
-                q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[tt], q[1], 0, 0, 0);
-                q[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[tt], q[2], 0, 0, 0);
-                q[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[tt], q[3], 0, 0, 0);
-                q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[tt], q[0], 0, 0, 0);
-                q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[tt], q[1], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][tt][4 * u + e] = q[u][e];
-            } else {
-                acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[tt], acc[i][tt], 0, 0, 0);
-                acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[tt], acc[i][tt], 0, 0, 0);
-                acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[tt], acc[i][tt], 0, 0, 0);
-            }
+        for (int ti = 0; ti < 2; ++ti) {
+            a.t[fi][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[fi], x.h[ti], a.t[fi][ti], 0, 0, 0);
+            a.t[fi][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[fi], x.h[ti], a.t[fi][ti], 0, 0, 0);
+            a.t[fi][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[fi], x.l[ti], a.t[fi][ti], 0, 0, 0);
         }
 }
+template <int NTW, int TTW, int TT>
+__device__ __forceinline__ void wt_mma(Acc32 (&acc)[NTW][TTW], const WFrag (&w)[NTW], const XFrag& x) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) wt_mma_block(acc[i][TT], w[i], x);
+}
 
-// Weight fragments of k-step `ks` for NTW tiles.  `wp[i]` and `ks` are wave-uniform (scalar registers), `lo8` is the
+// Weight fragments of k-step `ks` for NTW blocks.  `wp[i]` and `ks` are wave-uniform (scalar registers), `lo8` is the
 // lane's offset in halfs (lane * 8): the loads are global_load_dwordx4 with a scalar base, no per-load VALU.
 template <int NTW>
-__device__ __forceinline__ void w_load(half8 (&wh)[NTW], half8 (&wl)[NTW], const _Float16* const (&wp)[NTW], int ks,
-                                       unsigned lo8) {
+__device__ __forceinline__ void w_load(WFrag (&w)[NTW], const _Float16* const (&wp)[NTW], int ks, unsigned lo8) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const _Float16* p = wp[i] + (size_t)ks * (2 * WT_FRAG);
-        wh[i] = *reinterpret_cast<const half8*>(p + lo8);
-        wl[i] = *reinterpret_cast<const half8*>(p + WT_FRAG + lo8);
+        const _Float16* p = wp[i] + (size_t)ks * (4 * WT_FRAG);
+        w[i].h[0] = *reinterpret_cast<const half8*>(p + lo8);
+        w[i].l[0] = *reinterpret_cast<const half8*>(p + WT_FRAG + lo8);
+        w[i].h[1] = *reinterpret_cast<const half8*>(p + 2 * WT_FRAG + lo8);
+        w[i].l[1] = *reinterpret_cast<const half8*>(p + 3 * WT_FRAG + lo8);
     }
 }
 
@@ -185,18 +204,20 @@ __device__ unsigned long long g_stamps[1 << 22];
 #endif
 
 // ---------------------------------------------------------------- whole-K loop of one output tile
-// acc[i][tt] = sum_k W[(nt0 + i) tile][k] . X[m0 + tt tile][k], K in slabs of 64 (4 k-steps); weight fragments
-// D k-steps ahead in registers (D divides 4), the next activation slab one slab ahead in registers, two LDS
-// stages, one barrier per slab.  `smem`: XRing<TTW>::BYTES.
+// acc[i][tt] = sum_k W[(nt0 + i) block][k] . X[m0 + tt block][k], K in slabs of 64 (2 k-steps of 32); weight fragments
+// D k-steps ahead in registers (D = 1 or 2), the next activation slab one slab ahead in registers, two LDS stages, one
+// barrier per slab.  `smem`: XRing<TTW>::BYTES.  The fragments of the next (k-step, token block) unit are read from LDS
+// under the current unit's MFMAs.
 template <int NTW, int TTW, int D, bool ZERO = true>
-__device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16* __restrict__ Wp, int nt0, int K,
+__device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16* __restrict__ Wp, int nt0, int K,
                                          const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, int64_t m0,
                                          int64_t T, char* smem) {
-    static_assert(D == 1 || D == 2 || D == 4, "prefetch depth must divide the 4 k-steps of a slab");
+    static_assert(D == 1 || D == 2, "prefetch depth must divide the 2 k-steps of a slab");
+    static_assert(TTW == 1 || TTW == 2, "1 or 2 token blocks per wave");
     ICREC_STAMP(0, 0);
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const unsigned lo8 = lane * 8;
-    const int KS = K / 16, nslab = K / 64;
+    const int KS = K / 32, nslab = K / 64;
     const _Float16* wp[NTW];  // wave-uniform (nt0 must be)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) wp[i] = Wp + wt_frag_off(nt0 + i, 0, KS);
@@ -204,18 +225,15 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int tt = 0; tt < TTW; ++tt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][tt][e] = 0.0f;
+            for (int tt = 0; tt < TTW; ++tt) acc_zero(acc[i][tt]);
     }
-    half8 wh[D][NTW], wl[D][NTW];
+    WFrag w[D][NTW];
     // activation slabs: TWO in flight in registers (slab s+1 is written to LDS at the end of slab s, slab s+2 was
-    // requested a whole slab earlier) - with one, every slab boundary waited for an HBM round trip (stamps: the first
-    // slabs of a block took 2x the MFMA time)
+    // requested a whole slab earlier) - with one, every slab boundary waited for an HBM round trip
     u32x4 xa[2 * TTW], xb[2 * TTW];
     x_load<TTW>(xa, Xh, Xl, m0, T, K, 0);
 #pragma unroll
-    for (int d = 0; d < D; ++d) w_load<NTW>(wh[d], wl[d], wp, d, lo8);
+    for (int d = 0; d < D; ++d) w_load<NTW>(w[d], wp, d, lo8);
     if (nslab > 1) x_load<TTW>(xb, Xh, Xl, m0, T, K, 1);
     x_store<TTW>(xa, smem);
     if (nslab > 2) x_load<TTW>(xa, Xh, Xl, m0, T, K, 2);
@@ -223,26 +241,26 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
     ICREC_STAMP(0, 1);
     auto slab = [&](int s, u32x4 (&xnext)[2 * TTW]) {  // xnext holds slab s+1 on entry, slab s+3 on exit
         const char* st = smem + (s & 1) * XRing<TTW>::STAGE_BYTES;
-        half8 xh[2][TTW], xl[2][TTW];  // fragments of the next k-step are read under the current one's MFMAs
+        XFrag x[2];  // unit u = j * TTW + tt: the next unit's fragments are read under the current one's MFMAs
+        x_frag<TTW>(x[0], st, 0, 0, c, g);
 #pragma unroll
-        for (int tt = 0; tt < TTW; ++tt) {
-            xh[0][tt] = x_frag(st, tt, 0, r, h);
-            xl[0][tt] = x_frag(st + XRing<TTW>::PLANE_BYTES, tt, 0, r, h);
-        }
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < 3) {
-#pragma unroll
-                for (int tt = 0; tt < TTW; ++tt) {
-                    xh[(j + 1) & 1][tt] = x_frag(st, tt, j + 1, r, h);
-                    xl[(j + 1) & 1][tt] = x_frag(st + XRing<TTW>::PLANE_BYTES, tt, j + 1, r, h);
+            for (int tt = 0; tt < TTW; ++tt) {
+                constexpr int U = 2 * TTW;
+                const int u = j * TTW + tt;
+                if (u + 1 < U) {
+                    x_frag<TTW>(x[(u + 1) & 1], st, (u + 1) % TTW, (u + 1) / TTW, c, g);
+                    __builtin_amdgcn_sched_barrier(0);  // issue the next unit's LDS reads before this unit's MFMAs
                 }
+                if (tt == 0) wt_mma<NTW, TTW, 0>(acc, w[j % D], x[u & 1]);
+                else wt_mma<NTW, TTW, TTW - 1>(acc, w[j % D], x[u & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // keep every prefetch in its unit (the scheduler otherwise sinks the loads to their uses)
             }
-            wt_mma<NTW, TTW>(acc, wh[j % D], wl[j % D], xh[j & 1], xl[j & 1]);
-            int nk = 4 * s + j + D;  // past the end: re-read the last fragment (never consumed) - no branch in the loop body
+            int nk = 2 * s + j + D;  // past the end: re-read the last fragment (never consumed) - no branch in the loop body
             nk = nk < KS ? nk : KS - 1;
-            w_load<NTW>(wh[j % D], wl[j % D], wp, nk, lo8);
-            __builtin_amdgcn_sched_barrier(0);  // keep every prefetch in its k-step (the scheduler otherwise sinks the loads to their uses)
+            w_load<NTW>(w[j % D], wp, nk, lo8);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < nslab) {  // slab-granular (uniform) branches; the k-step body above is straight-line code
             x_store<TTW>(xnext, smem + ((s + 1) & 1) * XRing<TTW>::STAGE_BYTES);
@@ -256,9 +274,6 @@ __device__ __forceinline__ void wt_kloop(f32x16 (&acc)[NTW][TTW], const _Float16
         slab(s + 1, xa);
     }
 }
-
-// Feature (row of out^T) held in accumulator register e by a lane of half h: 8 (e >> 2) + 4 h + (e & 3).
-__device__ __forceinline__ int wt_feat(int e, int h) { return 8 * (e >> 2) + 4 * h + (e & 3); }
 
 #endif  // __HIPCC__
 

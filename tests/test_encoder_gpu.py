@@ -175,41 +175,37 @@ def test_two_stream_split_is_bitwise_identical(encoder):
 
 @pytest.mark.parametrize("n_seqs", [19, 400])
 def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, n_seqs):
-    """Batches above 512 tokens run attention-out + residual + LN and the whole FFN block (up, GELU, down,
-    residual, LN) as two fused kernels; ICREC_FUSE=0 runs the same arithmetic as separate GEMM / LayerNorm
-    launches and ICREC_FUSE=3 the persistent, block-pipelined form of the fused FFN kernel (400 sequences:
-    several blocks per workgroup, i.e. its pipelined block boundaries).  Same per-output MFMA chains and the same
-    LayerNorm order => identical bits."""
+    """Batches above 512 tokens run the activation-resident QKV kernel, attention with the longest-first dispatch
+    order, attention-out + residual + LN and the whole FFN block (up, GELU, down, residual, LN) as fused kernels.
+    An encoder created under ICREC_FUSE=0 (the switch is read once, at icrec_encoder_create) runs the UNFUSED
+    reference chain: slab-ring QKV, attention in batch order, separate GEMM / LayerNorm launches.  Same per-output
+    MFMA chains and the same LayerNorm order => identical bits (400 sequences: several rounds of workgroups)."""
     import torch
 
     from instacart_next_order_recommendation_amd import synthetic as syn
     from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
 
     enc = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    monkeypatch.setenv("ICREC_FUSE", "0")
+    ref = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    monkeypatch.delenv("ICREC_FUSE")
     ids, cu = syn.synthetic_token_batch(n_seqs, seed=5, mean_len=90, std_len=60, lo=3, hi=256)
     assert int(cu[-1]) > (512 if n_seqs == 19 else 2 * 64 * 256)
     mx = int(np.diff(cu).max())
     args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), mx)
     fused = enc.encode_packed(*args).cpu().numpy()
-    for mode in ("0", "3"):
-        monkeypatch.setenv("ICREC_FUSE", mode)
-        other = enc.encode_packed(*args).cpu().numpy()
-        monkeypatch.delenv("ICREC_FUSE")
-        np.testing.assert_array_equal(fused, other)
-    # the QKV projection: activation-resident kernel (default for batches) vs the slab-ring kernel;
-    # attention workgroups dispatched longest sequence first (default from 64 sequences) vs in batch order
-    for var in ("ICREC_QKV_RESIDENT", "ICREC_ATT_ORDER"):
-        monkeypatch.setenv(var, "0")
-        other = enc.encode_packed(*args).cpu().numpy()
-        monkeypatch.delenv(var)
-        np.testing.assert_array_equal(fused, other)
+    other = ref.encode_packed(*args).cpu().numpy()
+    np.testing.assert_array_equal(fused, other)
+    monkeypatch.setenv("ICREC_FUSE", "0")   # set AFTER creation: not read on the hot path, nothing changes
+    np.testing.assert_array_equal(enc.encode_packed(*args).cpu().numpy(), fused)
     enc.close()
+    ref.close()
 
 
 def test_side_stream_changes_nothing(minilm_weights, monkeypatch):
     """A batch of whole 64-token-per-CU rounds + a short remainder: the remainder's small-batch kernels and the short
     attention buckets run on the library's side stream (fork / join by events inside icrec_encode).
-    ICREC_SIDE_STREAM=0 keeps every kernel on the caller's stream: same bits, and repeated calls stay identical."""
+    An encoder created under ICREC_SIDE_STREAM=0 keeps every kernel on the caller's stream: same bits, and repeated calls stay identical."""
     import torch
 
     from instacart_next_order_recommendation_amd import _native, synthetic as syn
@@ -236,9 +232,11 @@ def test_side_stream_changes_nothing(minilm_weights, monkeypatch):
     args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), mx)
     a = enc.encode_packed(*args).cpu().numpy()
     b = enc.encode_packed(*args).cpu().numpy()
-    monkeypatch.setenv("ICREC_SIDE_STREAM", "0")
-    c = enc.encode_packed(*args).cpu().numpy()
+    monkeypatch.setenv("ICREC_SIDE_STREAM", "0")   # read once, at icrec_encoder_create
+    enc_one_stream = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
     monkeypatch.delenv("ICREC_SIDE_STREAM")
+    c = enc_one_stream.encode_packed(*args).cpu().numpy()
+    enc_one_stream.close()
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(a, c)
     # the remainder's sequences encode to the same bits on their own (small-batch kernels on the caller's stream)

@@ -14,6 +14,9 @@
 
 using namespace icrec;
 
+// the six attention-output arguments of ffn_fused2_kernel, unused when AO = false
+#define NOAO (const _Float16*)nullptr, (const _Float16*)nullptr, (const _Float16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr
+
 __global__ void fill_half(_Float16* p, size_t n, unsigned seed, float scale) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
@@ -127,18 +130,10 @@ int main(int argc, char** argv) {
         printf("==== T = %d (%d blocks of 64 tokens)\n", T, nb);
         auto kern = ffn_fused2_kernel<0>;
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f, NOAO);
         hipDeviceSynchronize();
         dump("ffn2 producer wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 26, 27, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
         dump("ffn2 consumer wave4", nb, 1, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 22, 23, 24, 25, 27, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
-        if (T >= 32768) {
-            auto k3 = ffn_fused3_kernel;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
-            for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k3, dim3(256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
-            hipDeviceSynchronize();
-            dump("ffn3 producer wave0 (2nd block)", 256, 0, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26});
-            dump("ffn3 consumer wave4 (2nd block)", 256, 1, {0, 1, 2, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26});
-        }
         if (T == 131072) {
             // shader clock under sustained load: s_memtime ticks between the first workgroup's start and the last one's end
             // of one launch, against that launch's duration by events; `burst` launches back to back before it
@@ -147,9 +142,9 @@ int main(int argc, char** argv) {
                 hipEventCreate(&ea); hipEventCreate(&eb);
                 hipDeviceSynchronize();
                 if (burst == 0) usleep(300000);
-                for (int rep = 0; rep < burst; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+                for (int rep = 0; rep < burst; ++rep) hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f, NOAO);
                 hipEventRecord(ea);
-                hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f, NOAO);
                 hipEventRecord(eb);
                 hipEventSynchronize(eb);
                 float ms; hipEventElapsedTime(&ms, ea, eb);
@@ -163,12 +158,19 @@ int main(int argc, char** argv) {
             }
         }
         reinit();
-        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
+        hipLaunchKernelGGL((wt_linear_kernel<3, 2, 1, 0>), dim3(nb * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         hipDeviceSynchronize();
         dump("qkv wave0", nb * 3, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
-        hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, xh, xl, g, bn, 1e-12f);
-        hipDeviceSynchronize();
-        dump("attn-out+LN wave0", nb, 0, {0, 1, 2, 3, 4, 5, 6, 7, 32, 33, 34, 35, 37, 38, 39, 40, 41, 42, 36, 30});
+        {
+            auto kao = ffn_fused2_kernel<0, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kao), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+            for (int rep = 0; rep < 2; ++rep)
+                hipLaunchKernelGGL(kao, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                                   (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn);
+            hipDeviceSynchronize();
+            dump("AO+ffn2 producer wave0", nb, 0, {0, 31, 1, 2, 3, 4, 5, 26, 27, 30});
+            dump("AO+ffn2 consumer wave4", nb, 1, {0, 31, 1, 2, 3, 4, 5, 27, 30});
+        }
         reinit();
         {   // attention, long bucket: 512 sequences of 200 tokens
             const int nseq = 512, Ls = 200;
@@ -222,58 +224,26 @@ int main(int argc, char** argv) {
     timeit("ffn_fused2 (producer/consumer) VAR=" #V, [&] {                                                               \
         auto kern = ffn_fused2_kernel<V>;                                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);  \
-        hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); \
+        hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f, NOAO); \
     }, ffn_flops)
         FFN2(0);
-        timeit("ffn_fused3 (persistent, pipelined blocks)", [&] {
-            auto kern = ffn_fused3_kernel;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
-            const int nb = (T + 63) / 64;
-            hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f);
-        }, ffn_flops);
-        if (T == 131072) {  // the two fused kernels timed interleaved (clocks drift over a run)
-            std::vector<Cand> cs;
-            const int nb = (T + 63) / 64;
-            { auto kern = ffn_fused2_kernel<0>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
-              cs.push_back({"ffn_fused2", [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
-            { auto kern = ffn_fused3_kernel; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
-              cs.push_back({"ffn_fused3", [=] { hipLaunchKernelGGL(kern, dim3(nb < 256 ? nb : 256), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
-            compare(cs, ffn_flops);
-        }
         if (T == T0 || T == 131072) {
-            FFN2(1); FFN2(4); FFN2(5); FFN2(13); FFN2(16);
-        }
-        if (T == 131072) {  // round-3 experiments, interleaved: MFMA shape (VAR 64, timing only) and half the weight stream (VAR 128)
-            std::vector<Cand> cs;
-            const int nb = (T + 63) / 64;
-#define CANDF(V, NAME) { auto kern = ffn_fused2_kernel<V>; hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS); \
-              cs.push_back({NAME, [=] { hipLaunchKernelGGL(kern, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f); }, {}}); }
-            CANDF(0, "ffn_fused2 product")
-            CANDF(64, "ffn_fused2 16x16x32 issue (timing only)")
-            CANDF(128, "ffn_fused2 half the weight loads (timing only)")
-            CANDF(192, "ffn_fused2 16x16x32 + half the weight loads")
-            CANDF(4, "ffn_fused2 no in-loop weight loads")
-            CANDF(68, "ffn_fused2 16x16x32 + no in-loop weight loads")
-            compare(cs, ffn_flops, 11);
+            FFN2(1); FFN2(4); FFN2(5); FFN2(13); FFN2(32);
         }
         reinit();
-        timeit("qkv wt_linear<3,2,2,0> N=1152", [&] {
-            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 2, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
+        timeit("qkv wt_linear<3,2,1,0> N=1152", [&] {
+            hipLaunchKernelGGL((wt_linear_kernel<3, 2, 1, 0>), dim3(((T + 63) / 64) * 3), dim3(256), 0, 0, xh, xl, T, H, Wqp, 3 * H, bq, qkv, nullptr, nullptr, 3);
         }, 2.0 * T * H * 3 * H);
         timeit("qkv_resident_kernel N=1152", [&] {
             hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QKVR_LDS);
             hipLaunchKernelGGL(qkv_resident_kernel, dim3((T + 63) / 64), dim3(512), QKVR_LDS, 0, xh, xl, T, Wqp, bq, qkv, 3 * H);
         }, 2.0 * T * H * 3 * H);
-        timeit("attn-out + LN wt_linear_ln<2>", [&] {
-            hipLaunchKernelGGL((wt_linear_ln_kernel<2>), dim3((T + 63) / 64), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, xh, xl, g, bn, 1e-12f);
-        }, 2.0 * T * H * H);
-        if (T == 131072) {
-            std::vector<Cand> cs;
-            const int nb = (T + 63) / 64;
-#define CANDAO(V) cs.push_back({"attn-out + LN VAR=" #V " (1: no residual in, 2: no LN / write-out)", [=] { hipLaunchKernelGGL((wt_linear_ln_kernel<2, V>), dim3(nb), dim3(256), 0, 0, ch, cl, T, H, Wop, b2, xh, xl, g, bn, 1e-12f); }, {}});
-            CANDAO(0) CANDAO(1) CANDAO(2) CANDAO(3)
-            compare(cs, 2.0 * T * H * H);
-        }
+        timeit("attn-out + LN + FFN in one kernel (AO)", [&] {
+            auto kern = ffn_fused2_kernel<0, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+            hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                               (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn);
+        }, ffn_flops + 2.0 * T * H * H);
         reinit();
         hipDeviceSynchronize();
     }
