@@ -45,11 +45,12 @@ __device__ __forceinline__ void gelu_split4(const f32x4& acc, const f32x4& bias,
 // ---------------------------------------------------------------- residual stream + LayerNorm of the f16x3 engine
 // In f16x3 mode the residual stream x lives in HBM ONLY as its two f16 planes (xh, xl: 16 x to 22 significant bits,
 // wt_gemm.h) — the planes every GEMM reads anyway.  The two LayerNorm sites of a layer (tf:292 attention output,
-// tf:350 FFN output: LN(dense(.) + bias + x)) start their accumulators from the residual instead of adding it at
-// the end:
-//     acc0 = fmaf(float(xh) + float(xl), 1024, bias * 2^14)      (hi + lo is exact in fp32; one rounding)
-//     acc  = acc0 + the k-steps of the GEMM, ascending           (units of 2^-14, like every accumulator of the engine)
-//     v    = acc * 2^-14                                         (exact)
+// tf:350 FFN output: LN(dense(.) + bias + x)) take the residual from those planes, in accumulator units:
+//     r    = fmaf(float(xh) + float(xl), 1024, bias * 2^14)      (hi + lo is exact in fp32; one rounding)
+//     acc  = the k-steps of the GEMM from 0, ascending           (units of 2^-14, like every accumulator of the engine)
+//     v    = (acc + r) * 2^-14                                   (one fp32 add; the scaling is exact)
+// (added AFTER the K loop: in the fused kernel the residual rows are staged by one half of the waves while the other
+// half runs the attention-output GEMM, and the two meet in one add)
 // then the engine's LayerNorm order over the 384 features of a token.  Wave q (0..3 of the waves holding
 // accumulators) owns features q*96 .. q*96+95: lane (c, g) holds, for token block tt and token half ti, the 24 values
 // of token tt*32 + ti*16 + c at features q*96 + i*32 + fi*16 + 4g + reg (i < 3, fi < 2, reg < 4):
@@ -58,7 +59,7 @@ __device__ __forceinline__ void gelu_split4(const f32x4& acc, const f32x4& bias,
 //   sum  = ((P0 + P1) + P2) + P3
 //   mean = sum / 384;   d = v - mean;   the same tree over fmaf(d, d, .) chains;   var = that / 384
 //   y = fmaf(d * (1 / sqrtf(var + eps)), gamma, beta);   planes = split(16 y)
-// (ln_wt_kernel is the unfused form with the same order — same bits.)
+// (wt_ln_block; ln_wt_kernel is the unfused form with the same order — same bits.)
 //
 // Global memory is touched only by coalesced accesses: a lane-per-token access pattern costs 4x the whole K loop
 // (in-kernel stamps, round 2).  Each wave transposes its own [32 tokens x 96 features] of one plane through a PRIVATE
@@ -84,68 +85,74 @@ __device__ __forceinline__ void lnt_flat(int lane, int k, int& row, int& c) {
     c = f - row * 12;
 }
 
-// acc0 of a [96-feature x 64-token] wave tile from the residual planes in global memory.  `tile`: this wave's
-// LNT_TILE bytes of LDS.
-__device__ __forceinline__ void wt_res_init_global(Acc32 (&acc)[3][2], int q, const float* __restrict__ bias,
-                                                   const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
-                                                   int64_t m0, int64_t T, char* tile) {
+// r (above) of a wave's [96 features x 32 tokens] (token block tb of the workgroup's 64) from the residual planes in
+// global memory, in two steps so that a caller can put work between the request and the use: wt_res_rows_load issues
+// the 12 coalesced 16-byte loads of the rows (12 lanes cover one token's 192 bytes of a plane), wt_res_rows_acc
+// transposes them through the wave's private LDS tile (`tile`: LNT_TILE bytes) into the accumulator layout:
+// acc[.][TT] = r (ADD = false) or += r (ADD = true).
+struct ResRows { u32x4 v[2][6]; };  // [plane][chunk]
+__device__ __forceinline__ void wt_res_rows_load(ResRows& rr, int q, int tb, const _Float16* __restrict__ xh,
+                                                 const _Float16* __restrict__ xl, int64_t m0, int64_t T) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int row, ch;
+        lnt_flat(lane, k, row, ch);
+        int64_t gr = m0 + tb * 32 + row;
+        gr = gr < T ? gr : T - 1;
+        const int64_t off = gr * 384 + q * 96 + ch * 8;
+        rr.v[0][k] = *reinterpret_cast<const u32x4*>(xh + off);
+        rr.v[1][k] = *reinterpret_cast<const u32x4*>(xl + off);
+    }
+}
+template <bool ADD, int TTW, int TT>
+__device__ __forceinline__ void wt_res_rows_acc(Acc32 (&acc)[3][TTW], const ResRows& rr, int q, const float* __restrict__ bias,
+                                                char* tile) {
     int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));  // opaque (see wt_ln_out)
+    asm volatile("" : "+v"(lane));  // opaque (see wt_ln_block)
     const int c = lane & 15, g = lane >> 4;
     int lpos[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {  // 16-B chunk f of the wave's [32 rows][12 chunks]: 12 lanes cover one row's 192 B
+    for (int k = 0; k < 6; ++k) {
         int row, ch;
         lnt_flat(lane, k, row, ch);
         lpos[k] = row * LNT_ROW + ch * 16;
     }
+    half4 hi[3][2][2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        u32x4 v[2][6];
+    for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int row, ch;
-            lnt_flat(lane, k, row, ch);
-            int64_t gr = m0 + tt * 32 + row;
-            gr = gr < T ? gr : T - 1;
-            const int64_t off = gr * 384 + q * 96 + ch * 8;
-            v[0][k] = *reinterpret_cast<const u32x4*>(xh + off);
-            v[1][k] = *reinterpret_cast<const u32x4*>(xl + off);
-        }
+        for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x4*>(tile + lpos[k]) = rr.v[pl][k];
+        lds_order();
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) *reinterpret_cast<u32x4*>(tile + lpos[k]) = v[pl][k];
-            lds_order();
+            for (int fi = 0; fi < 2; ++fi) {
+                const int fl = i * 32 + fi * 16 + 4 * g;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int ti = 0; ti < 2; ++ti) {
+                    const half4 a = *reinterpret_cast<const half4*>(tile + (ti * 16 + c) * LNT_ROW + fl * 2);
+                    if (pl == 0) {
+                        hi[i][fi][ti] = a;
+                    } else {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + q * 96 + fl);
 #pragma unroll
-                for (int fi = 0; fi < 2; ++fi) {
-                    const int fl = i * 32 + fi * 16 + 4 * g;
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
-                        const half4 a = *reinterpret_cast<const half4*>(tile + (ti * 16 + c) * LNT_ROW + fl * 2);
-                        if (pl == 0) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[i][tt].t[fi][ti][j] = (float)a[j];
-                        } else {
-                            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + q * 96 + fl);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)  // float(hi) + float(lo) is exact
-                                acc[i][tt].t[fi][ti][j] = fmaf(acc[i][tt].t[fi][ti][j] + (float)a[j], WT_SW, b[j] * (WT_SA * WT_SW));
+                        for (int j = 0; j < 4; ++j) {
+                            const float r = res_init_val(hi[i][fi][ti][j], a[j], b[j]);
+                            acc[i][TT].t[fi][ti][j] = ADD ? acc[i][TT].t[fi][ti][j] + r : r;
                         }
                     }
                 }
-            lds_order();
-        }
+            }
+        lds_order();
     }
 }
 
-// The same for the single-block waves of the small-batch kernels: 8-byte loads straight from global memory (a
+// acc += r for the single-block waves of the small-batch kernels: 8-byte loads straight from global memory (a
 // handful of tokens: latency, not bandwidth).
-__device__ __forceinline__ void wt_res_init_direct(Acc32 (&acc)[1][1], int nt0, const float* __restrict__ bias,
-                                                   const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
-                                                   int N, int64_t m0, int64_t T) {
+__device__ __forceinline__ void wt_res_add_direct(Acc32 (&acc)[1][1], int nt0, const float* __restrict__ bias,
+                                                  const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                  int N, int64_t m0, int64_t T) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) {
@@ -158,12 +165,12 @@ __device__ __forceinline__ void wt_res_init_direct(Acc32 (&acc)[1][1], int nt0, 
             const half4 a = *reinterpret_cast<const half4*>(xh + tok * N + feat);
             const half4 d = *reinterpret_cast<const half4*>(xl + tok * N + feat);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[0][0].t[fi][ti][j] = res_init_val(a[j], d[j], b[j]);
+            for (int j = 0; j < 4; ++j) acc[0][0].t[fi][ti][j] = acc[0][0].t[fi][ti][j] + res_init_val(a[j], d[j], b[j]);
         }
     }
 }
 
-// this thread's 16 bytes of the [gamma | beta] table wt_ln_out keeps in LDS (threads 0 .. 191 of the callers)
+// this thread's 16 bytes of the [gamma | beta] table wt_ln_block keeps in LDS (threads 0 .. 191 of the callers)
 __device__ __forceinline__ f32x4 wt_ln_par_load(const float* __restrict__ gam, const float* __restrict__ bet, int ptid) {
     const int t = ptid < 192 ? ptid : 0;
     return *reinterpret_cast<const f32x4*>((t < 96 ? gam : bet - 384) + 4 * t);
@@ -172,19 +179,22 @@ __device__ __forceinline__ f32x4 wt_ln_par_load(const float* __restrict__ gam, c
 constexpr int FFN2_XPLANE = 64 * 768;  // one plane of the resident activation image of the fused kernels (below)
 __device__ __forceinline__ int ffn_x_pos(int tok, int ch) { return tok * 768 + (((ch & ~15) | ((ch ^ tok) & 15)) << 4); }
 
-// LayerNorm of a block's accumulators (acc = residual + bias + dense, in units of 2^-14) -> the two planes of x,
-// written to global memory (xh / xl, rows m0 ..) or - xs != nullptr - into the resident activation image of the
-// fused kernel in LDS instead (layout ffn_x_pos; the caller's next barrier orders those writes against their readers).
-// NT threads call; `active` = this wave holds accumulators (wave-uniform), `sync` = the workgroup barrier.
-// lds: LNT_BYTES.  ptid: index of the thread among the callers (0 .. 191 must be present).
-template <class Sync>
-__device__ __forceinline__ void wt_ln_out(Acc32 (&acc)[3][2], bool active, int q, _Float16* __restrict__ xh,
-                                          _Float16* __restrict__ xl, int64_t m0, int64_t T,
-                                          const float* __restrict__ gam, const float* __restrict__ bet, float eps,
-                                          char* lds, Sync sync, int ptid, char* xs = nullptr) {
+// LayerNorm of ONE 32-token block held by four waves q = 0..3 (96 features each; accumulators acc[.][TT] = residual +
+// bias + dense in units of 2^-14) -> the two planes of x, written to global memory (xh / xl, rows m0 + tb*32 ..) or -
+// xs != nullptr - into the resident activation image of the fused kernel in LDS instead (layout ffn_x_pos; the caller's
+// next barrier orders those writes against their readers).  The fused kernel runs it on all eight waves at once: four
+// hold token block 0, four token block 1, every wave with a transposition tile of its own (`slot`).
+// Every thread of the workgroup calls; `sync` = the workgroup barrier (two of them).  lds: LNT_BYTES8 for eight slots.
+// ptid: index of the thread among the callers (0 .. 191 must be present).
+constexpr int LNT_BYTES8 = LNT_RED + 8 * LNT_TILE + LNT_PAR;   // 58,368 B
+template <int NSLOT, int TTW, int TT, class Sync>
+__device__ __forceinline__ void wt_ln_block(Acc32 (&acc)[3][TTW], int q, int tb, int slot, _Float16* __restrict__ xh,
+                                            _Float16* __restrict__ xl, int64_t m0, int64_t T,
+                                            const float* __restrict__ gam, const float* __restrict__ bet, float eps,
+                                            char* lds, Sync sync, int ptid, char* xs = nullptr) {
     float* const red = reinterpret_cast<float*>(lds);
-    char* const tile = lds + LNT_RED + q * LNT_TILE;
-    float* const par = reinterpret_cast<float*>(lds + LNT_RED + 4 * LNT_TILE);
+    char* const tile = lds + LNT_RED + slot * LNT_TILE;
+    float* const par = reinterpret_cast<float*>(lds + LNT_RED + NSLOT * LNT_TILE);
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));  // opaque: the per-lane addresses below are computed HERE, not hoisted to the kernel's
                                     // entry and held (or spilled) across the loops in front of this call
@@ -193,146 +203,118 @@ __device__ __forceinline__ void wt_ln_out(Acc32 (&acc)[3][2], bool active, int q
     // gamma / beta -> LDS (visible after the first barrier): each lane needs the 24 values of its quarter of the wave's
     // 96 features - as vector loads that is dozens of 1 KB requests through the texture path per wave for 768 distinct bytes
     if (ptid < 192) *reinterpret_cast<f32x4*>(par + 4 * ptid) = wt_ln_par_load(gam, bet, ptid);
-    if (active) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+    for (int ti = 0; ti < 2; ++ti) {
+        float part = 0.0f;
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                float part = 0.0f;
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-                    for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = acc[i][tt].t[fi][ti][e] * WT_UNSCALE;
-                            acc[i][tt].t[fi][ti][e] = v;
-                            part = part + v;
-                        }
-                part = part + __shfl_xor(part, 16, 64);
-                part = part + __shfl_xor(part, 32, 64);  // Pq: the same bits in the four lanes of a token
-                if (g == 0) red[(tt * 32 + ti * 16 + c) * 4 + q] = part;
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][TT].t[fi][ti][e] * WT_UNSCALE;
+                    acc[i][TT].t[fi][ti][e] = v;
+                    part = part + v;
+                }
+        part = part + __shfl_xor(part, 16, 64);
+        part = part + __shfl_xor(part, 32, 64);  // Pq: the same bits in the four lanes of a token
+        if (g == 0) red[(tb * 32 + ti * 16 + c) * 4 + q] = part;
     }
     ICREC_STAMP(0, 33); ICREC_STAMP(4, 33);
     sync();
-    if (active) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+    for (int ti = 0; ti < 2; ++ti) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + (tb * 32 + ti * 16 + c) * 4);
+        const float mean = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
+        float sq = 0.0f;
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + (tt * 32 + ti * 16 + c) * 4);
-                const float mean = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
-                float sq = 0.0f;
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-                    for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = acc[i][tt].t[fi][ti][e] - mean;
-                            acc[i][tt].t[fi][ti][e] = d;
-                            sq = fmaf(d, d, sq);
-                        }
-                sq = sq + __shfl_xor(sq, 16, 64);
-                sq = sq + __shfl_xor(sq, 32, 64);
-                if (g == 0) red[256 + (tt * 32 + ti * 16 + c) * 4 + q] = sq;
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[i][TT].t[fi][ti][e] - mean;
+                    acc[i][TT].t[fi][ti][e] = d;
+                    sq = fmaf(d, d, sq);
+                }
+        sq = sq + __shfl_xor(sq, 16, 64);
+        sq = sq + __shfl_xor(sq, 32, 64);
+        if (g == 0) red[256 + (tb * 32 + ti * 16 + c) * 4 + q] = sq;
     }
     ICREC_STAMP(0, 34); ICREC_STAMP(4, 34);
     sync();
     ICREC_STAMP(0, 35); ICREC_STAMP(4, 35);
-    if (active) {
+    float rstd[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {  // one 32-token block per pass
-            float rstd[2];
+    for (int ti = 0; ti < 2; ++ti) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + 256 + (tb * 32 + ti * 16 + c) * 4);
+        const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
+        rstd[ti] = 1.0f / sqrtf(var + eps);
+    }
+    const int64_t t0 = m0 + tb * 32;
+    half4 lo[3][2][2];
+    // the hi plane goes straight into the tile; lo waits in registers for its turn
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const int fl = i * 32 + fi * 16 + 4 * g;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(par + q * 96 + fl);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(par + 384 + q * 96 + fl);
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(red + 256 + (p * 32 + ti * 16 + c) * 4);
-                const float var = (((s4[0] + s4[1]) + s4[2]) + s4[3]) / 384.0f;
-                rstd[ti] = 1.0f / sqrtf(var + eps);
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][TT].t[fi][ti][j] * rstd[ti], gm[j], bt[j]);
+                half4 hi;
+                split_act4(y, hi, lo[i][fi][ti]);
+                *reinterpret_cast<half4*>(tile + (ti * 16 + c) * LNT_ROW + fl * 2) = hi;
             }
-            const int64_t t0 = m0 + p * 32;
-            half4 lo[3][2][2];
-            // the hi plane goes straight into the tile; lo waits in registers for its turn
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int fi = 0; fi < 2; ++fi) {
-                    const int fl = i * 32 + fi * 16 + 4 * g;
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(par + q * 96 + fl);
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(par + 384 + q * 96 + fl);
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
-                        f32x4 y;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = fmaf(acc[i][p].t[fi][ti][j] * rstd[ti], gm[j], bt[j]);
-                        half4 hi;
-                        split_act4(y, hi, lo[i][fi][ti]);
-                        *reinterpret_cast<half4*>(tile + (ti * 16 + c) * LNT_ROW + fl * 2) = hi;
-                    }
-                }
-            ICREC_STAMP(0, 37 + 3 * p); ICREC_STAMP(4, 37 + 3 * p);
-            lds_order();
-            u32x4 o[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int row, ch;
-                lnt_flat(lane, k, row, ch);
-                o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + ch * 16);
-            }
-            lds_order();
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti)
-                        *reinterpret_cast<half4*>(tile + (ti * 16 + c) * LNT_ROW + (i * 32 + fi * 16 + 4 * g) * 2) = lo[i][fi][ti];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {  // the hi rows leave while the lo tile is written
-                int row, ch;
-                lnt_flat(lane, k, row, ch);
-                if (xs != nullptr) *reinterpret_cast<u32x4*>(xs + ffn_x_pos(p * 32 + row, q * 12 + ch)) = o[k];
-                else if (t0 + row < T) *reinterpret_cast<u32x4*>(xh + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
-            }
-            lds_order();
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int row, ch;
-                lnt_flat(lane, k, row, ch);
-                o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + ch * 16);
-            }
-            lds_order();
-            ICREC_STAMP(0, 38 + 3 * p); ICREC_STAMP(4, 38 + 3 * p);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                int row, ch;
-                lnt_flat(lane, k, row, ch);
-                if (xs != nullptr) *reinterpret_cast<u32x4*>(xs + FFN2_XPLANE + ffn_x_pos(p * 32 + row, q * 12 + ch)) = o[k];
-                else if (t0 + row < T) *reinterpret_cast<u32x4*>(xl + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
-            }
-            ICREC_STAMP(0, 39 + 3 * p); ICREC_STAMP(4, 39 + 3 * p);
         }
+    lds_order();
+    u32x4 o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int row, ch;
+        lnt_flat(lane, k, row, ch);
+        o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + ch * 16);
+    }
+    lds_order();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+                *reinterpret_cast<half4*>(tile + (ti * 16 + c) * LNT_ROW + (i * 32 + fi * 16 + 4 * g) * 2) = lo[i][fi][ti];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // the hi rows leave while the lo tile is written
+        int row, ch;
+        lnt_flat(lane, k, row, ch);
+        if (xs != nullptr) *reinterpret_cast<u32x4*>(xs + ffn_x_pos(tb * 32 + row, q * 12 + ch)) = o[k];
+        else if (t0 + row < T) *reinterpret_cast<u32x4*>(xh + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
+    }
+    lds_order();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int row, ch;
+        lnt_flat(lane, k, row, ch);
+        o[k] = *reinterpret_cast<const u32x4*>(tile + row * LNT_ROW + ch * 16);
+    }
+    lds_order();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int row, ch;
+        lnt_flat(lane, k, row, ch);
+        if (xs != nullptr) *reinterpret_cast<u32x4*>(xs + FFN2_XPLANE + ffn_x_pos(tb * 32 + row, q * 12 + ch)) = o[k];
+        else if (t0 + row < T) *reinterpret_cast<u32x4*>(xl + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
     }
     ICREC_STAMP(0, 36); ICREC_STAMP(4, 36);
 }
 
-// What a wave WITHOUT accumulators does while the others run wt_ln_out (the producers of the fused kernel): its share
-// of the gamma / beta table and the two barriers.  A separate function (not wt_ln_out with active = false) so that no
-// accumulator array is live in such a wave across its own main loop.
-template <class Sync>
-__device__ __forceinline__ void wt_ln_bystander(const float* __restrict__ gam, const float* __restrict__ bet, char* lds,
-                                                Sync sync, int ptid) {
-    float* const par = reinterpret_cast<float*>(lds + LNT_RED + 4 * LNT_TILE);
-    if (ptid < 192) *reinterpret_cast<f32x4*>(par + 4 * ptid) = wt_ln_par_load(gam, bet, ptid);
-    sync();
-    sync();
-}
-
 // The unfused form of the same LayerNorm (small batches; the unfused reference chain): planes(x) <- LN(a), `a` =
 // dense(.) + bias + residual as the EPI 2 GEMM wrote it.  16 threads per token: thread (q, g) sums its 24 values in
-// (i, fi, reg) order, the 16 partials are combined by shuffles in the fixed tree of wt_ln_out.
+// (i, fi, reg) order, the 16 partials are combined by shuffles in the fixed tree of wt_ln_block.
 __global__ __launch_bounds__(256) void ln_wt_kernel(const float* __restrict__ a, int T, const float* __restrict__ gam,
                                                     const float* __restrict__ bet, float eps,
                                                     _Float16* __restrict__ xh, _Float16* __restrict__ xl) {
@@ -398,8 +380,8 @@ constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 1
 // token slab staged through LDS.  Block = 4 waves; wave q owns NTW 32-feature blocks x TTW 32-token blocks.
 //   EPI 0: out fp32 [T, N] = acc * 2^-14 + bias           (QKV)
 //   EPI 1: erf-GELU (tf:336), result as f16 hi/lo planes   (FFN-up of small batches)
-//   EPI 2: accumulators start from residual + bias (planes rh / rl, row stride N), out fp32 = acc * 2^-14: the
-//          LayerNorm input of attention-out / FFN-down for small batches (ln_wt_kernel follows)
+//   EPI 2: residual + bias (planes rh / rl, row stride N) added to the accumulators after the K loop, out fp32 =
+//          acc * 2^-14: the LayerNorm input of attention-out / FFN-down for small batches (ln_wt_kernel follows)
 // <1, 1, 2, EPI>: the small-batch form (<= 512 tokens and the remainder of a batch): 32-token x 128-feature
 // workgroups, latency-bound.  <3, 2, 1, EPI>: the 64-token x 384-feature form of the UNFUSED reference chain
 // (ICREC_FUSE=0: tests compare the fused kernels against it bit for bit).
@@ -421,16 +403,20 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
     const int64_t m0 = (int64_t)mt * (32 * TTW);
     const int nt0 = (nb * 4 + q) * NTW;
     Acc32 acc[NTW][TTW];
-    if constexpr (EPI == 2) {  // oh / ol carry the residual planes here
+    wt_kloop<NTW, TTW, D>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);  // ends with a barrier: the slab ring is free
+    if constexpr (EPI == 2) {  // oh / ol carry the residual planes here: acc += r
         if constexpr (NTW == 3 && TTW == 2) {
-            wt_res_init_global(acc, q, bias + nb * 384, oh + nb * 384, ol + nb * 384, m0, T, smem + q * LNT_TILE);
-            __syncthreads();
+            ResRows r0, r1;
+            wt_res_rows_load(r0, q, 0, oh + nb * 384, ol + nb * 384, m0, T);
+            wt_res_rows_load(r1, q, 1, oh + nb * 384, ol + nb * 384, m0, T);
+            wt_res_rows_acc<true, 2, 0>(acc, r0, q, bias + nb * 384, smem + q * LNT_TILE);
+            wt_res_rows_acc<true, 2, 1>(acc, r1, q, bias + nb * 384, smem + q * LNT_TILE);
+            __syncthreads();  // the private tiles become the output stage
         } else {
-            static_assert(NTW == 1 && TTW == 1, "residual init: 3 x 2 or 1 x 1 wave tiles");
-            wt_res_init_direct(acc, nt0, bias, oh, ol, N, m0, T);
+            static_assert(NTW == 1 && TTW == 1, "residual: 3 x 2 or 1 x 1 wave tiles");
+            wt_res_add_direct(acc, nt0, bias, oh, ol, N, m0, T);
         }
     }
-    wt_kloop<NTW, TTW, D, EPI != 2>(acc, Wp, nt0, K, Xh, Xl, m0, T, smem);
     if constexpr (STAGED) {
         // [384 features x 32 tokens] per pass -> stage[token][feature] (16-B LDS writes), then 16-B chunks in flat
         // order: every wave store instruction writes 1 KB of at most two output rows
@@ -503,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_kernel(const _Float16* __res
 // [64 tokens][384 k] halfs per plane in LDS: 768-B rows as three 256-B sub-rows, 16-B chunk ch of token row t at
 // sub-row ch >> 4, slot (ch ^ t) & 15.  A fragment read of token half ti, k-step ks — lane (c, g): row ti*16 + c (+ 32 tt),
 // chunk 4 ks + g — puts the 16 lanes of every ds_read_b128 lane group on 16 distinct slots.
-constexpr int FFN2_X_BYTES = 2 * FFN2_XPLANE;            // hi, lo (FFN2_XPLANE / ffn_x_pos: defined above wt_ln_out)
+constexpr int FFN2_X_BYTES = 2 * FFN2_XPLANE;            // hi, lo (FFN2_XPLANE / ffn_x_pos: defined above wt_ln_block)
 
 // the block's activation planes -> LDS (NT threads, all of them call)
 template <int NT>
@@ -578,12 +564,12 @@ __device__ __forceinline__ void bar_lds() {  // LDS hand-off barrier that leaves
 //
 // AO = true (the product): the kernel is the whole post-attention half of a layer.  Its prologue is the attention
 // output projection + residual + LayerNorm (tf:289-293) of the same 64 tokens:
-//   the block's CONTEXT planes (ch / cl) go to the resident image; the four consumer waves - they already own the
-//   [96 features x 64 tokens] accumulator layout and its LayerNorm epilogue - start from residual + bias (x planes from
-//   global memory, wt_res_init_global), run K = 384 over Wo (12 k-steps, the P2 loop over the other image) and
-//   LayerNorm straight into the resident image: x1 = LN(Wo . ctx + bo + x) never travels to HBM (-2 x 768 B per
-//   token per layer each way, one launch fewer), the FFN proceeds on it as before.  Per output the same chain and the
-//   same LayerNorm order as wt_linear_kernel<.., 2> + ln_wt_kernel: identical bits.
+//   the block's CONTEXT planes (ch / cl) go to the resident image; the producer waves run K = 384 over Wo while the
+//   consumer waves - they own the [96 features x 64 tokens] accumulator layout and its LayerNorm epilogue - stage
+//   residual + bias; the consumers add the two and LayerNorm straight into the resident image: x1 = LN(Wo . ctx + bo
+//   + x) never travels to HBM (-2 x 768 B per token per layer each way, one launch fewer), the FFN proceeds on it as
+//   before.  Per output the same chain and the same LayerNorm order as wt_linear_kernel<.., 2> + ln_wt_kernel:
+//   identical bits.
 // VAR (tools/ffn_bench.hip only; the product uses 0), timing ablations: 1 = no GELU, 4 = no in-loop weight loads,
 // 8 = no in-loop LDS fragment reads, 32 = no sched_group_barrier interleave
 template <int VAR, bool AO = false>
@@ -613,52 +599,128 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
 
     ICREC_STAMP(0, 0);
     ICREC_STAMP(4, 0);
-    const unsigned lo8 = lane * 8;
+    unsigned lo8 = lane * 8;
     if constexpr (AO) {
-        ffn_x_stage<512>(Xs, ch, cl, m0, T);  // the context planes
-        __syncthreads();
-        // x1 = LayerNorm(Wo . ctx + bo + x) -> the resident image (the LayerNorm's two barriers order the last fragment
-        // reads of the context planes before the first write; the "X resident" barrier below publishes it).
-        // Scratch: the H buffers, idle until then.
-        if (producer) {
-            wt_ln_bystander(gam1, bet1, Hs, [] { __syncthreads(); }, tid);
-        } else {
-            Acc32 Y[3][2];
-            const _Float16* wop[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) wop[i] = Wop + wt_frag_off(q * 3 + i, 0, KS1);
-            wt_res_init_global(Y, q, bo, xh, xl, m0, T, Hs + LNT_RED + q * LNT_TILE);  // per-wave private tiles: no barrier
-            WFrag w[2][3];  // requested after the residual rows: beside their staging registers the ring would spill
-#pragma unroll
-            for (int d = 0; d < 2; ++d) w_load<3>(w[d], wop, d, lo8);
+        // x1 = LayerNorm(Wo . ctx + bo + x) -> the resident image.
+        // All eight waves share the work; wave (q, half) owns features q*96 .. +95 of token block `half`:
+        //  * it stages its residual rows into the accumulator layout (global -> its private LDS tile -> r);
+        //  * the GEMM runs in the producers' form (one 32-feature block x 64 tokens at a time, weight ring 4 k-steps deep,
+        //    the loop of qkv_resident_kernel): producer p takes blocks p and p + 4, consumer q block 8 + q - two waves
+        //    per SIMD, each covering the other's waits;
+        //  * the products travel through the context image, dead once every wave has left its K loops: 12 blocks x 2
+        //    token blocks x 4 tiles x 1 KB = the 96 KB of the image, each tile in the lane order both sides hold it in
+        //    (conflict-free 16-B accesses); every wave picks up the 12 tiles of its (q, half), adds r and takes part in
+        //    the LayerNorm of its token block, which lands in the image.
+        // Scratch (LayerNorm exchange, eight transposition tiles): the H buffers, idle until the FFN starts.
+        // (the two roles run the same steps from separate instantiations: a value defined on one path only - the early
+        // residual rows, a ring - would otherwise be carried, and spilled, along the other path too)
+        auto prologue = [&](auto role_tag) {
+            constexpr bool PROD = decltype(role_tag)::value;
+            constexpr int tb = PROD ? 0 : 1;  // the token block this wave stages, adds and normalises
+            ResRows rr;  // the wave's residual rows.  Consumers (one GEMM block, registers to spare): requested first of
+                         // all, they arrive under the staging of the context planes and are transposed before the K
+                         // loop.  Producers (two blocks: beside two accumulator sets, the ring and the fragments the
+                         // rows would spill): requested behind the K loops - they finish first and wait anyway.
+            if (!PROD) wt_res_rows_load(rr, q, tb, xh, xl, m0, T);
+            ffn_x_stage<512>(Xs, ch, cl, m0, T);  // the context planes
             int xb[2][2];
             ffn_x_bases(xb, c, g);
-            XFrag x[2];  // unit u = 2 ks + tt
-            ffn_x_frag(x[0], Xs, xb, 0, 0);
+            WFrag w[4][1];
+            {
+                const _Float16* const wp0[1] = {Wop + wt_frag_off(PROD ? q : 8 + q, 0, KS1)};
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int u = 2 * ks + tt;
-                    if (u + 1 < 2 * KS1) {
-                        ffn_x_frag(x[(u + 1) & 1], Xs, xb, (u + 1) & 1, (u + 1) >> 1);
-                        __builtin_amdgcn_sched_barrier(0);  // issue the next unit's LDS reads before this unit's 36 MFMAs
-                    }
-                    if (tt == 0) wt_mma<3, 2, 0>(Y, w[ks & 1], x[u & 1]);
-                    else wt_mma<3, 2, 1>(Y, w[ks & 1], x[u & 1]);
-                }
-                w_load<3>(w[ks & 1], wop, ks + 2 < KS1 ? ks + 2 : KS1 - 1, lo8);  // past the end: re-read (never consumed)
-                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+                for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp0, d, lo8);
             }
+            __syncthreads();  // context planes resident
+            // K = 384 of one block; the ring continues into block `nn` (or re-reads this one's last fragments, never consumed)
+            auto ao_block = [&](Acc32 (&S)[2], int nt, int nn) {
+                const _Float16* const wp1[1] = {Wop + wt_frag_off(nt, 0, KS1)};
+                const _Float16* const wpn[1] = {Wop + wt_frag_off(nn, 0, KS1)};
+                acc_zero(S[0]);
+                acc_zero(S[1]);
+                XFrag x[2];
+                ffn_x_frag(x[0], Xs, xb, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int u = 2 * ks + tt;
+                        if (u + 1 < 2 * KS1) {
+                            ffn_x_frag(x[(u + 1) & 1], Xs, xb, (u + 1) & 1, (u + 1) >> 1);
+                            __builtin_amdgcn_sched_barrier(0);  // the next unit's LDS reads before this unit's 12 MFMAs
+                        }
+                        wt_mma_block(S[tt], w[ks & 3][0], x[u & 1]);
+                    }
+                    if (ks + 4 < KS1) w_load<1>(w[ks & 3], wp1, ks + 4, lo8);
+                    else w_load<1>(w[ks & 3], wpn, ks + 4 - KS1, lo8);
+                    __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+                }
+            };
+            auto put = [&](const Acc32 (&S)[2], int nt) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti)
+                            *reinterpret_cast<f32x4*>(Xs + (((nt * 2 + tt) * 2 + fi) * 2 + ti) * 1024 + lane * 16) = S[tt].t[fi][ti];
+            };
+            Acc32 Y[3][1];
+            auto finish_r = [&]() {  // r is FINISHED here: otherwise the compiler sinks the final fma of every element below
+                                     // the barriers and carries its two inputs instead
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti) asm volatile("" : "+v"(Y[i][0].t[fi][ti]));
+            };
+            if constexpr (PROD) {
+                Acc32 S0[2], S1[2];
+                ao_block(S0, q, q + 4);
+                ao_block(S1, q + 4, q + 4);
+                ICREC_STAMP(0, 28);
+                wt_res_rows_load(rr, q, tb, xh, xl, m0, T);
+                __syncthreads();  // every wave has left the context image: it takes the products
+                put(S0, q);
+                put(S1, q + 4);
+                wt_res_rows_acc<false, 1, 0>(Y, rr, q, bo, Hs + LNT_RED + wave * LNT_TILE);  // per-wave private tiles
+                finish_r();
+            } else {
+                wt_res_rows_acc<false, 1, 0>(Y, rr, q, bo, Hs + LNT_RED + wave * LNT_TILE);
+                finish_r();
+                Acc32 S2[2];
+                ao_block(S2, 8 + q, 8 + q);
+                ICREC_STAMP(4, 28);
+                __syncthreads();  // every wave has left the context image
+                put(S2, 8 + q);
+            }
+            __syncthreads();  // products visible
+            ICREC_STAMP(0, 29);
+            ICREC_STAMP(4, 29);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(Xs + ((((q * 3 + i) * 2 + tb) * 2 + fi) * 2 + ti) * 1024 + lane * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Y[i][0].t[fi][ti][j] = sv[j] + Y[i][0].t[fi][ti][j];  // acc + r
+                    }
             ICREC_STAMP(4, 31);
-            wt_ln_out(Y, true, q, nullptr, nullptr, m0, T, gam1, bet1, eps, Hs, [] { __syncthreads(); }, tid, Xs);
-        }
+            // its first barrier also orders every wave's reads of the products before the first write of x1
+            wt_ln_block<8, 1, 0>(Y, q, tb, wave, nullptr, nullptr, m0, T, gam1, bet1, eps, Hs, [] { __syncthreads(); }, tid, Xs);
+        };
+        if (producer) prologue(std::true_type{});
+        else prologue(std::false_type{});
         ICREC_STAMP(0, 31);
     } else {
         ffn_x_stage<512>(Xs, xh, xl, m0, T);
     }
-    if constexpr (AO) {  // the FFN part's per-lane addresses are derived from here on (not hoisted above the prologue)
-        asm volatile("" : "+v"(c), "+v"(g));
+    if constexpr (AO) {  // the FFN part's per-lane addresses - and with them its first weight-ring loads, 96 registers in
+                         // the consumers - are derived from here on, not hoisted above the prologue (where they spill)
+        asm volatile("" : "+v"(c), "+v"(g), "+v"(lo8));
     }
     if (producer) {
         int xb[2][2];
@@ -759,9 +821,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
         bar_lds();  // B(NC): H[NC - 1]
         ICREC_STAMP(0, 26);
         ICREC_STAMP(0, 27);
-        // ---- the consumers' LayerNorm: the producers only join its barriers
-        __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm scratch
-        wt_ln_bystander(gam, bet, smem2, [] { __syncthreads(); }, tid);
+        // ---- the LayerNorm of token block 1: its accumulators come over from the consumers through the H buffers
+        __syncthreads();  // every reader of the LDS is done: image and H buffers are free
+        __syncthreads();  // token block 1 parked
+        Acc32 Yp[3][1];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+                    Yp[i][0].t[fi][ti] = *reinterpret_cast<const f32x4*>(Hs + ((q * 12) + (i * 2 + fi) * 2 + ti) * 1024 + lane * 16);
+        wt_ln_block<8, 1, 0>(Yp, q, 1, wave, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, tid);
     } else {
         Acc32 Y[3][2];
         const _Float16* w2p[3];
@@ -777,25 +848,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
         for (int d = 0; d < 2; ++d) w_load<3>(w[d], w2p, d, lo8);
         __syncthreads();  // X resident (matches the producers' first barrier)
         ICREC_STAMP(4, 1);
-        // Y starts from the residual + bias: the block's own planes, already in LDS (wt_res_init_*: same value)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {
-                const int feat = q * 96 + i * 32 + fi * 16 + 4 * g;  // 4 consecutive features: half a 16-B chunk
-                const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + feat);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
-                        const int tok = tt * 32 + ti * 16 + c;
-                        const int pos = ffn_x_pos(tok, feat >> 3) + 8 * (g & 1);
-                        const half4 a = *reinterpret_cast<const half4*>(Xs + pos);
-                        const half4 d = *reinterpret_cast<const half4*>(Xs + FFN2_XPLANE + pos);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) Y[i][tt].t[fi][ti][j] = res_init_val(a[j], d[j], b[j]);
-                    }
-            }
+            for (int tt = 0; tt < 2; ++tt) acc_zero(Y[i][tt]);
         bar_lds();        // B1: H[0] is ready
         for (int ch = 0; ch < NC; ++ch) {
             ICREC_STAMP(4, 2 + 2 * ch);
@@ -833,9 +889,37 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
             if (ch + 1 < NC) bar_lds();  // B(ch+2): done with H[ch & 1]; H[(ch + 1) & 1] is ready
         }
         ICREC_STAMP(4, 27);
-        // ---- LayerNorm on the consumers' accumulators
-        __syncthreads();  // every reader of the LDS is done: it becomes the LayerNorm scratch
-        wt_ln_out(Y, true, q, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, tid);
+        // ---- + residual + bias: the block's own planes, still resident (the same r as wt_res_global / wt_res_add_direct)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {
+                const int feat = q * 96 + i * 32 + fi * 16 + 4 * g;  // 4 consecutive features: half a 16-B chunk
+                const f32x4 b = *reinterpret_cast<const f32x4*>(b2 + feat);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti) {
+                        const int tok = tt * 32 + ti * 16 + c;
+                        const int pos = ffn_x_pos(tok, feat >> 3) + 8 * (g & 1);
+                        const half4 a = *reinterpret_cast<const half4*>(Xs + pos);
+                        const half4 d = *reinterpret_cast<const half4*>(Xs + FFN2_XPLANE + pos);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Y[i][tt].t[fi][ti][j] = Y[i][tt].t[fi][ti][j] + res_init_val(a[j], d[j], b[j]);
+                    }
+            }
+        // ---- LayerNorm: token block 0 here, token block 1 on the producer wave of the same q (idle otherwise): its
+        // accumulators are parked in the H buffers (12 tiles of 1 KB per wave, lane order)
+        __syncthreads();  // every reader of the LDS is done: image and H buffers are free
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+                    *reinterpret_cast<f32x4*>(Hs + ((q * 12) + (i * 2 + fi) * 2 + ti) * 1024 + lane * 16) = Y[i][1].t[fi][ti];
+        __syncthreads();  // token block 1 parked
+        wt_ln_block<8, 2, 0>(Y, q, 0, wave, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, tid);
     }
     ICREC_STAMP(0, 30);
     ICREC_STAMP(4, 30);

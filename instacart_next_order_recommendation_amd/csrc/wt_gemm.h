@@ -208,7 +208,7 @@ __device__ unsigned long long g_stamps[1 << 22];
 // D k-steps ahead in registers (D = 1 or 2), the next activation slab one slab ahead in registers, two LDS stages, one
 // barrier per slab.  `smem`: XRing<TTW>::BYTES.  The fragments of the next (k-step, token block) unit are read from LDS
 // under the current unit's MFMAs.
-template <int NTW, int TTW, int D, bool ZERO = true>
+template <int NTW, int TTW, int D>
 __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16* __restrict__ Wp, int nt0, int K,
                                          const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, int64_t m0,
                                          int64_t T, char* smem) {
@@ -221,12 +221,10 @@ __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16*
     const _Float16* wp[NTW];  // wave-uniform (nt0 must be)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) wp[i] = Wp + wt_frag_off(nt0 + i, 0, KS);
-    if (ZERO) {  // !ZERO: the caller has put the residual + bias into the accumulators (wt_res_init_*)
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int tt = 0; tt < TTW; ++tt) acc_zero(acc[i][tt]);
-    }
+        for (int tt = 0; tt < TTW; ++tt) acc_zero(acc[i][tt]);
     WFrag w[D][NTW];
     // activation slabs: TWO in flight in registers (slab s+1 is written to LDS at the end of slab s, slab s+2 was
     // requested a whole slab earlier) - with one, every slab boundary waited for an HBM round trip

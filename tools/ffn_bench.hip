@@ -168,8 +168,8 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL(kao, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
                                    (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn);
             hipDeviceSynchronize();
-            dump("AO+ffn2 producer wave0", nb, 0, {0, 31, 1, 2, 3, 4, 5, 26, 27, 30});
-            dump("AO+ffn2 consumer wave4", nb, 1, {0, 31, 1, 2, 3, 4, 5, 27, 30});
+            dump("AO+ffn2 producer wave0", nb, 0, {0, 28, 29, 31, 1, 2, 3, 4, 5, 26, 27, 30});
+            dump("AO+ffn2 consumer wave4", nb, 1, {0, 28, 29, 31, 1, 2, 3, 4, 5, 27, 30});
         }
         reinit();
         {   // attention, long bucket: 512 sequences of 200 tokens
