@@ -133,18 +133,20 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
                 "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
     peak = PEAK_F16_MFMA_TFLOPS / 3.0
     traffic, note = load_traffic("ffn_fused2_kernel")
-    w_bytes = (2 * 1536 * 384 + 384 * 384) * 2 * 2  # W1, W2, Wo as packed hi/lo f16 fragments
+    w_bytes = (2 * 1536 * 384 + 384 * 384 + 5 / 6 * 1152 * 384) * 2 * 2  # W1, W2, Wo (+ 5/6 Wqkv) as packed hi/lo f16 fragments
     l2_bytes = (tokens // 64) * (w_bytes + 64 * 384 * 4 * 2 + 6 * 1024)
-    return {"kernel": "ffn_fused2_kernel<0, AO> (attention-out + residual + LayerNorm, then FFN-up + erf-GELU + FFN-down + "
-                      "residual + LayerNorm, all on chip; 3x v_mfma_f32_16x16x32_f16 per product, weights streamed L2 -> registers)",
+    return {"kernel": "ffn_fused2_kernel<0, AO> = the whole post-attention part of a layer in one launch: attention-out + residual "
+                      "+ LayerNorm, FFN-up + erf-GELU + FFN-down + residual + LayerNorm, then the NEXT layer's QKV projection "
+                      "(5 of the 6 launches of a step), all on chip; 3x v_mfma_f32_16x16x32_f16 per product, weights streamed "
+                      "L2 -> registers",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "peak_note": "fp32-accurate product = 3 f16 MFMAs, so the algorithm's MFMA roof is 2500/3 TFLOP/s of "
                          "algorithmic FLOPs; against the raw f16 dense peak the fraction is frac_of_f16_dense_peak",
             "frac_of_f16_dense_peak": achieved / PEAK_F16_MFMA_TFLOPS,
             "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
-            "algorithmic_bytes": tokens * 384 * (4 + 4 + 4) + w_bytes,
-            "algorithmic_bytes_note": "context planes in + x planes in (residual) + x planes out (2 x 2 B/elt each), + the "
-                                      "layer's packed Wo/W1/W2 fragments once",
+            "algorithmic_bytes": tokens * 384 * (4 + 4 + 4) + tokens * 1152 * 4 * 5 / 6 + w_bytes,
+            "algorithmic_bytes_note": "context planes in + x planes in (residual) + x planes out (2 x 2 B/elt each) + fp32 "
+                                      "Q/K/V rows out (5 of 6 launches), + the layer's packed Wo/W1/W2 (+ next Wqkv) fragments once",
             "ceiling_note": "a registers-only loop of the same MFMA instruction on RANDOM operands sustains 1,970 TFLOP/s f16 "
                             "dense on this chip at 1.95 GHz (tools/mfma_shape.hip, profiles/r03_mfma_shape_microbench.txt; the "
                             "32x32x16 form the engine used before: 1,710 at 1.69 GHz; both reach 2,450 on all-zero operands): "
@@ -526,8 +528,11 @@ def main() -> None:
                           "icrec_encode_batch_split")
         ffn_tokens = int(t_main.value)
         # algorithmic FLOPs per timed launch: FFN-up only in f32 mode; attention-out + FFN-up + FFN-down in the fused kernel
+        # (+ the next layer's QKV projection in all but the last layer's launch: the figure is the average over a step's launches)
+        n_l = shape.layers
         ffn_flops = 2.0 * ffn_tokens * shape.hidden * shape.intermediate if enc.gemm_mode == "f32" else \
-            ffn_tokens * (4.0 * shape.hidden * shape.intermediate + 2.0 * shape.hidden * shape.hidden)
+            ffn_tokens * (4.0 * shape.hidden * shape.intermediate + 2.0 * shape.hidden * shape.hidden
+                          + (n_l - 1) / n_l * 2.0 * shape.hidden * 3 * shape.hidden)
         achieved = ffn_flops / (ffn_ms * 1e-3) / 1e12 if ffn_ms > 0 else 0.0
         out = {
             "metric": "recommend_qps_top20_49k7_catalog" if args.workload == "49k7" else "recommend_qps_top20_10m_catalog",

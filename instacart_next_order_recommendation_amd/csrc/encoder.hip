@@ -1034,8 +1034,13 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     const int nblk = (Tn + 63) / 64;
                     auto kern = ffn_fused2_kernel<0, true>;
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), FFN2_LDS)) return rc_;
+                    // ... and, but for the last layer, the NEXT layer's QKV projection of the rows it has just normalised
+                    const bool next_qkv = l + 1 < c.layers;
+                    const LayerW& Ln = e->layers[next_qkv ? l + 1 : l];
                     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), FFN2_LDS, st, xhr, xlr, Tn, I, L.W1_p, L.b1, L.W2_p,
-                                       L.b2, L.g2, L.b2n, c.ln_eps, chr, clr, L.Wo_p, L.bo, L.g1, L.b1n);
+                                       L.b2, L.g2, L.b2n, c.ln_eps, chr, clr, L.Wo_p, L.bo, L.g1, L.b1n,
+                                       next_qkv ? (const _Float16*)Ln.Wqkv_p : (const _Float16*)nullptr, (const float*)Ln.bqkv,
+                                       qkv + (size_t)r0 * 3 * H, 3 * H);
                 } else {
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
                     launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes
@@ -1066,7 +1071,11 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             } else if (T_tail) {
                 if (int rc_ = qkv_stage(T_main, T_tail, st)) return rc_;
             }
-            if (int rc_ = qkv_stage(0, T_main, st)) return rc_;
+            // batches: layer 0 projects Q / K / V in a launch of its own; every later layer's projection is the epilogue of
+            // the previous layer's fused kernel
+            const bool qkv_in_fused = fuse && T_main > X3_SMALL_M && H == 384;
+            if (l == 0 || !qkv_in_fused)
+                if (int rc_ = qkv_stage(0, T_main, st)) return rc_;
             if (T_tail && use_side) ICREC_HIP(hipStreamWaitEvent(st, sd->ev_qkv_tail, 0));
             if (split_att && use_side) {
                 // the long bucket keeps one 8-wave workgroup per CU busy (LDS) with issue slots to spare: the shorter

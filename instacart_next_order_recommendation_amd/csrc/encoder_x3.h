@@ -180,9 +180,9 @@ constexpr int FFN2_XPLANE = 64 * 768;  // one plane of the resident activation i
 __device__ __forceinline__ int ffn_x_pos(int tok, int ch) { return tok * 768 + (((ch & ~15) | ((ch ^ tok) & 15)) << 4); }
 
 // LayerNorm of ONE 32-token block held by four waves q = 0..3 (96 features each; accumulators acc[.][TT] = residual +
-// bias + dense in units of 2^-14) -> the two planes of x, written to global memory (xh / xl, rows m0 + tb*32 ..) or -
-// xs != nullptr - into the resident activation image of the fused kernel in LDS instead (layout ffn_x_pos; the caller's
-// next barrier orders those writes against their readers).  The fused kernel runs it on all eight waves at once: four
+// bias + dense in units of 2^-14) -> the two planes of x, written to global memory (xh / xl != nullptr: rows m0 + tb*32 ..)
+// and / or - xs != nullptr - into the resident activation image of the fused kernel in LDS (layout ffn_x_pos; the
+// caller's next barrier orders those writes against their readers).  The fused kernel runs it on all eight waves at once: four
 // hold token block 0, four token block 1, every wave with a transposition tile of its own (`slot`).
 // Every thread of the workgroup calls; `sync` = the workgroup barrier (two of them).  lds: LNT_BYTES8 for eight slots.
 // ptid: index of the thread among the callers (0 .. 191 must be present).
@@ -292,7 +292,7 @@ __device__ __forceinline__ void wt_ln_block(Acc32 (&acc)[3][TTW], int q, int tb,
         int row, ch;
         lnt_flat(lane, k, row, ch);
         if (xs != nullptr) *reinterpret_cast<u32x4*>(xs + ffn_x_pos(tb * 32 + row, q * 12 + ch)) = o[k];
-        else if (t0 + row < T) *reinterpret_cast<u32x4*>(xh + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
+        if (xh != nullptr && t0 + row < T) *reinterpret_cast<u32x4*>(xh + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
     }
     lds_order();
 #pragma unroll
@@ -307,7 +307,7 @@ __device__ __forceinline__ void wt_ln_block(Acc32 (&acc)[3][TTW], int q, int tb,
         int row, ch;
         lnt_flat(lane, k, row, ch);
         if (xs != nullptr) *reinterpret_cast<u32x4*>(xs + FFN2_XPLANE + ffn_x_pos(tb * 32 + row, q * 12 + ch)) = o[k];
-        else if (t0 + row < T) *reinterpret_cast<u32x4*>(xl + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
+        if (xl != nullptr && t0 + row < T) *reinterpret_cast<u32x4*>(xl + (t0 + row) * 384 + q * 96 + ch * 8) = o[k];
     }
     ICREC_STAMP(0, 36); ICREC_STAMP(4, 36);
 }
@@ -532,6 +532,91 @@ __device__ __forceinline__ void ffn_x_frag(XFrag& x, const char* Xs, const int (
     }
 }
 
+// ---------------------------------------------------------------- QKV projection, activation-resident form (large batches)
+// out[T, N] = X . W^T + bias for a block of 64 tokens and ALL N = 1,152 features on the eight waves of a workgroup,
+// built like the producer half of the fused kernel: the block's 64 x 384 activation planes are resident in LDS (96 KB),
+// every wave walks whole 32-feature blocks - wave w: blocks w, w + 8, ... (a SIMD hosts waves s and s + 4 = 9 of the
+// 36 blocks) - with K = 384 as 12 straight-line k-steps, the weight ring 4 k-steps deep and running across block
+// boundaries, no workgroup barrier.  Results leave through a private per-wave LDS tile ([32 tokens][32 features] fp32,
+// 144-B rows) as 16-B chunks: 128 B per token row per store.
+// Per output the MFMA chain is wt_kloop's: the same bits as wt_linear_kernel<3, 2, 1, 0>.
+// Two callers: qkv_resident_kernel (layer 0, after the embeddings) and the fused post-attention kernel, which ends
+// with the NEXT layer's projection of the block it has just normalised.
+constexpr int QKVR_STG_LD = 36;                                  // floats per staged row (+16 B)
+constexpr int QKVR_STG_BYTES = 32 * QKVR_STG_LD * 4;             // 4,608 B per wave
+constexpr int QKVR_LDS = FFN2_X_BYTES + 8 * QKVR_STG_BYTES;      // 135,168 B
+
+__device__ __forceinline__ void qkv_block_walk(const char* Xs, float* stg, const _Float16* __restrict__ Wp,
+                                               const float* __restrict__ bias, float* __restrict__ out, int N, int64_t m0,
+                                               int64_t T, int wave, int lane, int c, int g, unsigned lo8) {
+    constexpr int KS1 = 12;
+    const int NT = N / 32;
+    int xb[2][2];
+    ffn_x_bases(xb, c, g);
+    WFrag w[4][1];
+    {
+        const _Float16* const wp0[1] = {Wp + wt_frag_off(wave, 0, KS1)};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp0, d, lo8);
+    }
+    for (int nt = wave; nt < NT; nt += 8) {
+        const int nn = nt + 8 < NT ? nt + 8 : nt;  // past the last block: re-read this one's fragments (never consumed)
+        const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
+        const _Float16* const wpn[1] = {Wp + wt_frag_off(nn, 0, KS1)};
+        f32x4 bv[2];  // loaded BEFORE the k-loop (vmcnt counts in order: behind the ring it would wait for the whole ring)
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) bv[fi] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + fi * 16 + 4 * g);
+        Acc32 S[1][2];
+        acc_zero(S[0][0]);
+        acc_zero(S[0][1]);
+        XFrag x[2];
+        ffn_x_frag(x[0], Xs, xb, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int u = 2 * ks + tt;
+                if (u + 1 < 2 * KS1) {
+                    ffn_x_frag(x[(u + 1) & 1], Xs, xb, (u + 1) & 1, (u + 1) >> 1);
+                    __builtin_amdgcn_sched_barrier(0);  // the next unit's LDS reads are issued before this unit's 12 MFMAs
+                }
+                if (tt == 0) wt_mma<1, 2, 0>(S, w[ks & 3], x[u & 1]);
+                else wt_mma<1, 2, 1>(S, w[ks & 3], x[u & 1]);
+            }
+            if (ks + 4 < KS1) w_load<1>(w[ks & 3], wp1, ks + 4, lo8);
+            else w_load<1>(w[ks & 3], wpn, ks + 4 - KS1, lo8);
+            __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+        }
+        // ---- this block out: [32 tokens][32 features] per pass through the wave's private LDS tile
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(S[0][tt].t[fi][ti][j], WT_UNSCALE, bv[fi][j]);
+                    *reinterpret_cast<f32x4*>(stg + (ti * 16 + c) * QKVR_STG_LD + fi * 16 + 4 * g) = v;
+                }
+            lds_order();
+            f32x4 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = lane + 64 * k;
+                o[k] = *reinterpret_cast<const f32x4*>(stg + (f >> 3) * QKVR_STG_LD + (f & 7) * 4);
+            }
+            lds_order();  // the tile is free for the next pass before the stores are issued
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = lane + 64 * k;
+                const int64_t tok = m0 + tt * 32 + (f >> 3);
+                if (tok < T) *reinterpret_cast<f32x4*>(out + tok * N + nt * 32 + (f & 7) * 4) = o[k];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- fused FFN (large batches)
 // x <- LN(W2 . gelu(W1 . x + b1) + b2 + x)   (tf:334-351: BertIntermediate, BertOutput) for a block of 64 tokens,
 // without the [T, 1536] intermediate ever leaving the CU.  The 1,536 intermediate features are walked in 12 chunks
@@ -586,7 +671,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                                                             const _Float16* __restrict__ Wop = nullptr,
                                                             const float* __restrict__ bo = nullptr,
                                                             const float* __restrict__ gam1 = nullptr,
-                                                            const float* __restrict__ bet1 = nullptr) {
+                                                            const float* __restrict__ bet1 = nullptr,
+                                                            const _Float16* __restrict__ Wqp = nullptr,
+                                                            const float* __restrict__ bq = nullptr,
+                                                            float* __restrict__ qkv_out = nullptr, int Nq = 0) {
     constexpr int KS1 = 12;  // k-steps of 32 over K = 384
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     char* const Xs = smem2;
@@ -821,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
         bar_lds();  // B(NC): H[NC - 1]
         ICREC_STAMP(0, 26);
         ICREC_STAMP(0, 27);
-        // ---- the LayerNorm of token block 1: its accumulators come over from the consumers through the H buffers
+        // ---- the LayerNorm of token block 1: its accumulators come over from the consumers through the (dead) image
         __syncthreads();  // every reader of the LDS is done: image and H buffers are free
         __syncthreads();  // token block 1 parked
         Acc32 Yp[3][1];
@@ -831,8 +919,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
             for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
-                    Yp[i][0].t[fi][ti] = *reinterpret_cast<const f32x4*>(Hs + ((q * 12) + (i * 2 + fi) * 2 + ti) * 1024 + lane * 16);
-        wt_ln_block<8, 1, 0>(Yp, q, 1, wave, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, tid);
+                    Yp[i][0].t[fi][ti] = *reinterpret_cast<const f32x4*>(Xs + ((q * 12) + (i * 2 + fi) * 2 + ti) * 1024 + lane * 16);
+        // scratch: the H buffers; x2 goes to global memory and - when the next layer's QKV projection follows - into the
+        // image (written behind the LayerNorm's barriers: every parked tile has been picked up by then)
+        wt_ln_block<8, 1, 0>(Yp, q, 1, wave, xh, xl, m0, T, gam, bet, eps, Hs, [] { __syncthreads(); }, tid, Wqp != nullptr ? Xs : nullptr);
     } else {
         Acc32 Y[3][2];
         const _Float16* w2p[3];
@@ -909,7 +999,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                     }
             }
         // ---- LayerNorm: token block 0 here, token block 1 on the producer wave of the same q (idle otherwise): its
-        // accumulators are parked in the H buffers (12 tiles of 1 KB per wave, lane order)
+        // accumulators are parked in the dead image (12 tiles of 1 KB per wave, lane order)
         __syncthreads();  // every reader of the LDS is done: image and H buffers are free
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -917,105 +1007,37 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
             for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
-                    *reinterpret_cast<f32x4*>(Hs + ((q * 12) + (i * 2 + fi) * 2 + ti) * 1024 + lane * 16) = Y[i][1].t[fi][ti];
+                    *reinterpret_cast<f32x4*>(Xs + ((q * 12) + (i * 2 + fi) * 2 + ti) * 1024 + lane * 16) = Y[i][1].t[fi][ti];
         __syncthreads();  // token block 1 parked
-        wt_ln_block<8, 2, 0>(Y, q, 0, wave, xh, xl, m0, T, gam, bet, eps, smem2, [] { __syncthreads(); }, tid);
+        wt_ln_block<8, 2, 0>(Y, q, 0, wave, xh, xl, m0, T, gam, bet, eps, Hs, [] { __syncthreads(); }, tid, Wqp != nullptr ? Xs : nullptr);
     }
     ICREC_STAMP(0, 30);
     ICREC_STAMP(4, 30);
+    // ---- the NEXT layer's QKV projection of this block (tf:175-177), on the planes just normalised, still on chip: no
+    // separate launch, no re-read of x, and the 4.6 KB of fp32 Q / K / V rows per token leave spread over the whole
+    // kernel's time instead of in one burst.  Staging tiles: the H buffers (the LayerNorm scratch is done with).
+    if (Wqp != nullptr) {  // uniform over the grid
+        __syncthreads();  // x2 resident in the image; LayerNorm scratch free
+        asm volatile("" : "+v"(c), "+v"(g), "+v"(lo8));  // (addresses and first ring loads derived here, not hoisted)
+        qkv_block_walk(Xs, reinterpret_cast<float*>(Hs + wave * QKVR_STG_BYTES), Wqp, bq, qkv_out, Nq, m0, T, wave, lane, c, g, lo8);
+    }
+    ICREC_STAMP(0, 43);
+    ICREC_STAMP(4, 43);
 }
-
-// ---------------------------------------------------------------- QKV projection, activation-resident form (large batches)
-// out[T, N] = X . W^T + bias for a block of 64 tokens and ALL N = 1,152 features in one 8-wave workgroup, built like
-// the producer half of ffn_fused2_kernel: the block's 64 x 384 activation planes are loaded into LDS ONCE (96 KB),
-// every wave walks whole 32-feature blocks - wave w: blocks w, w + 8, ... (a SIMD hosts waves s and s + 4 = 9 of the
-// 36 blocks) - with K = 384 as 12 straight-line k-steps, the weight ring 4 k-steps deep and running across block
-// boundaries, no workgroup barrier after the first.  Results leave through a private per-wave LDS tile
-// ([32 tokens][32 features] fp32, 144-B rows) as 16-B chunks: 128 B per token row per store.
-// Per output the MFMA chain is wt_kloop's: the same bits as wt_linear_kernel<3, 2, 1, 0>.
-constexpr int QKVR_STG_LD = 36;                                  // floats per staged row (+16 B)
-constexpr int QKVR_STG_BYTES = 32 * QKVR_STG_LD * 4;             // 4,608 B per wave
-constexpr int QKVR_LDS = FFN2_X_BYTES + 8 * QKVR_STG_BYTES;      // 135,168 B
 
 __global__ __launch_bounds__(512, 2) void qkv_resident_kernel(const _Float16* __restrict__ xh,
                                                               const _Float16* __restrict__ xl, int T,
                                                               const _Float16* __restrict__ Wp,
                                                               const float* __restrict__ bias,
                                                               float* __restrict__ out, int N) {
-    constexpr int KS1 = 12;
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     char* const Xs = smem2;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), c = lane & 15, g = lane >> 4;
     float* const stg = reinterpret_cast<float*>(smem2 + FFN2_X_BYTES + wave * QKVR_STG_BYTES);
     const int64_t m0 = (int64_t)blockIdx.x * 64;
-    const int NT = N / 32;
     ffn_x_stage<512>(Xs, xh, xl, m0, T);
-    const unsigned lo8 = lane * 8;
-    int xb[2][2];
-    ffn_x_bases(xb, c, g);
-    WFrag w[4][1];
-    {
-        const _Float16* const wp0[1] = {Wp + wt_frag_off(wave, 0, KS1)};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp0, d, lo8);
-    }
     __syncthreads();  // X resident
-    for (int nt = wave; nt < NT; nt += 8) {
-        const int nn = nt + 8 < NT ? nt + 8 : nt;  // past the last block: re-read this one's fragments (never consumed)
-        const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
-        const _Float16* const wpn[1] = {Wp + wt_frag_off(nn, 0, KS1)};
-        f32x4 bv[2];  // loaded BEFORE the k-loop (vmcnt counts in order: behind the ring it would wait for the whole ring)
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi) bv[fi] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + fi * 16 + 4 * g);
-        Acc32 S[1][2];
-        acc_zero(S[0][0]);
-        acc_zero(S[0][1]);
-        XFrag x[2];
-        ffn_x_frag(x[0], Xs, xb, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int u = 2 * ks + tt;
-                if (u + 1 < 2 * KS1) {
-                    ffn_x_frag(x[(u + 1) & 1], Xs, xb, (u + 1) & 1, (u + 1) >> 1);
-                    __builtin_amdgcn_sched_barrier(0);  // the next unit's LDS reads are issued before this unit's 12 MFMAs
-                }
-                if (tt == 0) wt_mma<1, 2, 0>(S, w[ks & 3], x[u & 1]);
-                else wt_mma<1, 2, 1>(S, w[ks & 3], x[u & 1]);
-            }
-            if (ks + 4 < KS1) w_load<1>(w[ks & 3], wp1, ks + 4, lo8);
-            else w_load<1>(w[ks & 3], wpn, ks + 4 - KS1, lo8);
-            __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
-        }
-        // ---- this block out: [32 tokens][32 features] per pass through the wave's private LDS tile
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaf(S[0][tt].t[fi][ti][j], WT_UNSCALE, bv[fi][j]);
-                    *reinterpret_cast<f32x4*>(stg + (ti * 16 + c) * QKVR_STG_LD + fi * 16 + 4 * g) = v;
-                }
-            lds_order();
-            f32x4 o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int f = lane + 64 * k;
-                o[k] = *reinterpret_cast<const f32x4*>(stg + (f >> 3) * QKVR_STG_LD + (f & 7) * 4);
-            }
-            lds_order();  // the tile is free for the next pass before the stores are issued
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int f = lane + 64 * k;
-                const int64_t tok = m0 + tt * 32 + (f >> 3);
-                if (tok < T) *reinterpret_cast<f32x4*>(out + tok * N + nt * 32 + (f & 7) * 4) = o[k];
-            }
-        }
-    }
+    qkv_block_walk(Xs, stg, Wp, bias, out, N, m0, T, wave, lane, c, g, lane * 8);
 }
 
 // W (fp32 [N, K]) -> packed f16 hi/lo fragments (wt_gemm.h), once at encoder creation.

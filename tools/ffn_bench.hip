@@ -15,7 +15,8 @@
 using namespace icrec;
 
 // the six attention-output arguments of ffn_fused2_kernel, unused when AO = false
-#define NOAO (const _Float16*)nullptr, (const _Float16*)nullptr, (const _Float16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr
+#define NOQKV (const _Float16*)nullptr, (const float*)nullptr, (float*)nullptr, 0
+#define NOAO (const _Float16*)nullptr, (const _Float16*)nullptr, (const _Float16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, NOQKV
 
 __global__ void fill_half(_Float16* p, size_t n, unsigned seed, float scale) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -166,10 +167,10 @@ int main(int argc, char** argv) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kao), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
             for (int rep = 0; rep < 2; ++rep)
                 hipLaunchKernelGGL(kao, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
-                                   (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn);
+                                   (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn, NOQKV);
             hipDeviceSynchronize();
-            dump("AO+ffn2 producer wave0", nb, 0, {0, 28, 29, 31, 1, 2, 3, 4, 5, 26, 27, 30});
-            dump("AO+ffn2 consumer wave4", nb, 1, {0, 28, 29, 31, 1, 2, 3, 4, 5, 27, 30});
+            dump("AO+ffn2 producer wave0", nb, 0, {0, 28, 29, 31, 1, 2, 3, 4, 5, 26, 27, 30, 43});
+            dump("AO+ffn2 consumer wave4", nb, 1, {0, 28, 29, 31, 1, 2, 3, 4, 5, 27, 30, 43});
         }
         reinit();
         {   // attention, long bucket: 512 sequences of 200 tokens
@@ -242,8 +243,15 @@ int main(int argc, char** argv) {
             auto kern = ffn_fused2_kernel<0, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
             hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
-                               (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn);
+                               (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn, NOQKV);
         }, ffn_flops + 2.0 * T * H * H);
+        timeit("attn-out + LN + FFN + next layer's QKV in one kernel", [&] {
+            auto kern = ffn_fused2_kernel<0, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+            hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                               (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
+                               (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
+        }, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H);
         reinit();
         hipDeviceSynchronize();
     }
