@@ -348,12 +348,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
     }
 }
 
+// nlo: sequences of nlo < nkt <= NKT key tiles belong to this launch (the others' workgroups exit at once)
 template <int NKT, int WAVES, bool SPLIT>
-__global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void attention_x3_kernel(const float* __restrict__ qkv,
                                                                   const int32_t* __restrict__ cu, int heads, int H,
                                                                   float scale_log2e, float* __restrict__ ctx,
                                                                   _Float16* __restrict__ ch, _Float16* __restrict__ cl,
-                                                                  const int32_t* __restrict__ order) {
+                                                                  const int32_t* __restrict__ order, int nlo) {
     // Single-accumulator form of the split (wt_gemm.h): every operand is carried as hi/lo f16 planes of 16 x (Q, K, V)
     // or 1024 p (the probabilities), the three products of a k-step accumulate into ONE fp32 tile, and the power-of-two
     // scales are folded into constants: S' = 256 S, O' = 16384 sum_k p_k V_k, l' = 1024 sum_k p_k, O = O' / (16 l').
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
     // per wave on an idle matrix pipe, and the kernel drops under 128 VGPRs; with the output tile parked on the K
     // planes (behind one more barrier) it also drops to 67 KB of LDS - TWO workgroups per CU, so one's staging and
     // barrier phases run under the other's arithmetic.
-    constexpr bool RECOMP = NKT >= 8;
+    constexpr bool RECOMP = NKT >= 6;
     constexpr int VT = NKT * 32 + 4;  // V^T row stride in halfs (+8 B: the 32 dims land on distinct banks)
     __shared__ __attribute__((aligned(16))) _Float16 Kbuf[2 * NKT * 32 * 32];
     _Float16* const Kh = Kbuf;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
     const int s = order != nullptr ? order[sidx] : sidx;  // seq_order_kernel: longest first
     const int t0 = cu[s], L = cu[s + 1] - t0;
     const int nkt = (L + 31) >> 5;
-    if (nkt > NKT || (NKT > 1 && nkt <= NKT / 2)) return;  // another bucket's sequence
+    if (nkt > NKT || nkt <= nlo) return;  // another bucket's sequence
     const int qb0 = blockIdx.y * WAVES;
     if (qb0 >= nkt) return;
     const int ld = 3 * H;
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 8 ? 4 : 1)) void attention_x3_k
         }
     }
     // K/V staging: all of this thread's loads are issued before the first one is consumed
-    constexpr int STG = NKT * 32 * 8 / (WAVES * 64);  // = 4 for every bucket
+    constexpr int STG = NKT * 32 * 8 / (WAVES * 64);  // = 4 for every bucket (WAVES == NKT)
+    static_assert(NKT * 32 * 8 % (WAVES * 64) == 0, "staging: whole rounds");
     f32x4 kreg[STG], vreg[STG];
 #pragma unroll
     for (int it = 0; it < STG; ++it) {
@@ -798,15 +800,20 @@ static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, in
     const int nkt_max = (max_seqlen + 31) / 32;
     const bool single = n_seqs == 1;
     const dim3 grid1(n_seqs * heads, 1);
-#define ICREC_ATT(NKT, W)                                                                                        \
+#define ICREC_ATT(NKT, W, NLO)                                                                                   \
     do {                                                                                                         \
-        if (X3) hipLaunchKernelGGL((attention_x3_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl, order); \
+        if (X3) hipLaunchKernelGGL((attention_x3_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl, order, NLO); \
         else hipLaunchKernelGGL((attention_kernel<NKT, W, SPLIT>), grid1, dim3(W * 64), 0, st, qkv, cu, heads, H, sl2e, ctx, ch, cl);      \
     } while (0)
-    if ((buckets & 1) && (single ? nkt_max == 1 : true)) ICREC_ATT(1, 1);
-    if ((buckets & 2) && (single ? nkt_max == 2 : nkt_max >= 2)) ICREC_ATT(2, 2);
-    if ((buckets & 4) && (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)) ICREC_ATT(4, 4);
-    if ((buckets & 8) && nkt_max >= 5) ICREC_ATT(8, 8);
+    if ((buckets & 1) && (single ? nkt_max == 1 : true)) ICREC_ATT(1, 1, 0);
+    if ((buckets & 2) && (single ? nkt_max == 2 : nkt_max >= 2)) ICREC_ATT(2, 2, 1);
+    if ((buckets & 4) && (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)) ICREC_ATT(4, 4, 2);
+    if (X3 && !single) {  // f16x3 batches: the long sequences in two buckets (5-6 and 7-8 key tiles)
+        if ((buckets & 8) && nkt_max >= 5) ICREC_ATT(6, 6, 4);
+        if ((buckets & 8) && nkt_max >= 7) ICREC_ATT(8, 8, 6);
+    } else if ((buckets & 8) && nkt_max >= 5) {
+        ICREC_ATT(8, 8, 4);
+    }
 #undef ICREC_ATT
 }
 

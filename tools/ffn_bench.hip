@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
             fill_float<<<1024, 256>>>(qkv, (size_t)nseq * Ls * 3 * H, 21, 2.0f);
             const float sl2e = (1.0f / sqrtf(32.0f)) * 1.44269504088896340736f;
             for (int rep = 0; rep < 2; ++rep)
-                hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr);
+                hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 4);
             hipDeviceSynchronize();
             dump("attention long (L=200) wave0", nseq * 12, 0, {0, 1, 2, 3, 4, 5});
             {   // per-CU timeline: how much of a CU's span is covered by 0 / 1 / 2 resident workgroups
@@ -211,7 +211,7 @@ int main(int argc, char** argv) {
                        100 * cov[2] / span, 100 * cov[3] / span, (double)nblk / ev.size(), life / nblk);
             }
             timeit("attention_x3<8,8> 512 seq x 200 tok", [&] {
-                hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr);
+                hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 4);
             }, 4.0 * nseq * 12 * Ls * Ls * 32);
             hipFree(cud);
         }
