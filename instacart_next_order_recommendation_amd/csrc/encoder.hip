@@ -793,9 +793,10 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
 // costs a few microseconds; single-sequence calls launch exactly one bucket).
 template <bool SPLIT, bool X3>
 static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, int heads, int H, int max_seqlen,
-                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st, int buckets = 15,
+                             float* ctx, _Float16* ch, _Float16* cl, hipStream_t st, int buckets = 31,
                              const int32_t* order = nullptr) {
-    // buckets: bit b set = launch the bucket of 2^b key tiles (callers split the buckets over two streams)
+    // buckets: bits 0..2 = the 1-, 2-, 3-4-tile buckets, bit 3 = 5-6 tiles (5-8 outside f16x3 batches), bit 4 = 7-8 tiles
+    // (callers split the buckets over two streams)
     const float sl2e = (1.0f / sqrtf((float)DH)) * 1.44269504088896340736f;
     const int nkt_max = (max_seqlen + 31) / 32;
     const bool single = n_seqs == 1;
@@ -810,7 +811,7 @@ static void launch_attention(const float* qkv, const int32_t* cu, int n_seqs, in
     if ((buckets & 4) && (single ? (nkt_max == 3 || nkt_max == 4) : nkt_max >= 3)) ICREC_ATT(4, 4, 2);
     if (X3 && !single) {  // f16x3 batches: the long sequences in two buckets (5-6 and 7-8 key tiles)
         if ((buckets & 8) && nkt_max >= 5) ICREC_ATT(6, 6, 4);
-        if ((buckets & 8) && nkt_max >= 7) ICREC_ATT(8, 8, 6);
+        if ((buckets & 16) && nkt_max >= 7) ICREC_ATT(8, 8, 6);
     } else if ((buckets & 8) && nkt_max >= 5) {
         ICREC_ATT(8, 8, 4);
     }
@@ -1089,12 +1090,12 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 // buckets' workgroups run beside it from the side stream instead of after it
                 ICREC_HIP(hipEventRecord(sd->ev_q, st));
                 ICREC_HIP(hipStreamWaitEvent(sd->side, sd->ev_q, 0));
-                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, sd->side, 7, order);
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, sd->side, 7 | 16, order);
                 ICREC_HIP(hipEventRecord(sd->ev_sa, sd->side));
                 launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 8, order);
                 ICREC_HIP(hipStreamWaitEvent(st, sd->ev_sa, 0));
             } else {
-                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 15, order);
+                launch_attention<true, true>(qkv, cu_dev, n_seqs, c.heads, H, max_seqlen, ctx, ch, cl, st, 31, order);
             }
             if (T_tail) {
                 if (use_side) {

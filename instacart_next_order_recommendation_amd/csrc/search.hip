@@ -861,6 +861,7 @@ struct Index {
     int64_t row_offset = 0;
     int device = 0;
     int n_cu = 256;
+    int stream_max_q = 8;          // ICREC_STREAM_MAX_Q at creation
 };
 
 static inline bool rows_are_bf16(const Index* ix) { return ix->storage == ICREC_ROWS_BF16 || ix->storage == ICREC_ROWS_BF16_FILTER; }
@@ -895,16 +896,12 @@ struct Plan {
     size_t ws_q, ws_partial, ws_total;
 };
 
-// Largest batch the streaming kernel takes (ICREC_STREAM_MAX_Q=0 disables it; tuning/diagnostic knob).
-static int stream_max_q() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ICREC_STREAM_MAX_Q");
-        v = e ? atoi(e) : 8;
-        if (v > 8) v = 8;
-        if (v < 0) v = 0;
-    }
-    return v;
+// Largest batch the streaming kernel takes (ICREC_STREAM_MAX_Q=0 disables it; tuning/diagnostic knob), read ONCE,
+// when the index is created: a handle never changes its kernels between calls.
+static int stream_max_q_from_env() {
+    const char* e = getenv("ICREC_STREAM_MAX_Q");
+    const int v = e ? atoi(e) : 8;
+    return v > 8 ? 8 : v < 0 ? 0 : v;
 }
 
 static Plan make_plan(const Index* ix, int Q, int k, bool allow_stream) {
@@ -913,7 +910,7 @@ static Plan make_plan(const Index* ix, int Q, int k, bool allow_stream) {
     // over several tiles: take it for Q <= 2 always, for Q <= 8 once every block has >= 2 tiles (measured at
     // 49,688 rows, f32: Q=8 67 us streaming vs 44 us MFMA; at 2M rows 0.64 ms vs 0.76 ms).
     const int64_t st_tiles = (ix->n_rows + ST_ROWS - 1) / ST_ROWS;
-    if (allow_stream && Q <= stream_max_q() && (Q <= 2 || st_tiles >= 2 * 3 * (int64_t)ix->n_cu)) {
+    if (allow_stream && Q <= ix->stream_max_q && (Q <= 2 || st_tiles >= 2 * 3 * (int64_t)ix->n_cu)) {
         // variant 3: stream_search_kernel<NQ>, one block per chunk of 256-row tiles, no query tiling
         const int nq = Q <= 1 ? 1 : Q <= 2 ? 2 : Q <= 4 ? 4 : 8;
         p.variant = 3; p.BM = ST_ROWS; p.BN = nq;
@@ -1245,6 +1242,7 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     Index* ix = new Index();
     ix->n_rows = n_rows; ix->dim = dim; ix->row_offset = row_offset; ix->device = device; ix->storage = storage;
     ix->n_cu = prop.multiProcessorCount;
+    ix->stream_max_q = stream_max_q_from_env();
     const size_t bytes = (size_t)n_rows * dim * (rows16 ? 2 : 4);
     hipError_t e = hipMalloc(&ix->rows, bytes);
     if (e != hipSuccess) {
