@@ -310,10 +310,11 @@ __global__ __launch_bounds__(1024) void seq_order_kernel(const int32_t* __restri
     const int tid = threadIdx.x;
     for (int i = tid; i < 257; i += 1024) hist[i] = 0;
     __syncthreads();
-    for (int s = tid; s < n_seqs; s += 1024) {
+    for (int s0 = tid; s0 < n_seqs; s0 += 1024) {
+        const int s = n_seqs - 1 - s0;
         int L = cu[s + 1] - cu[s];
         L = L < 1 ? 1 : (L > 256 ? 256 : L);
-        atomicAdd(&hist[256 - L], 1);
+        atomicAdd(&hist[256 - ((L + 31) & ~31)], 1);
     }
     __syncthreads();
     if (tid == 0) {  // exclusive prefix sum: hist[b] becomes the first slot of bin b
@@ -321,10 +322,11 @@ __global__ __launch_bounds__(1024) void seq_order_kernel(const int32_t* __restri
         for (int b = 0; b < 257; ++b) { const int c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
-    for (int s = tid; s < n_seqs; s += 1024) {
+    for (int s0 = tid; s0 < n_seqs; s0 += 1024) {
+        const int s = n_seqs - 1 - s0;
         int L = cu[s + 1] - cu[s];
         L = L < 1 ? 1 : (L > 256 ? 256 : L);
-        order[atomicAdd(&hist[256 - L], 1)] = s;
+        order[atomicAdd(&hist[256 - ((L + 31) & ~31)], 1)] = s;
     }
 }
 

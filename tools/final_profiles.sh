@@ -19,7 +19,7 @@ python tools/pmc_summary.py $O/pmc_a > $O/pmc_per_kernel.txt
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_f -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_f.err && echo pmc-f-ok
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_w -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_w.err && echo pmc-w-ok
 python tools/pmc_bytes.py $O/pmc_f $O/pmc_w > $O/pmc_hbm_bytes.txt
-python tools/pmc_traffic_json.py $O/pmc_f $O/pmc_w $O/roofline_traffic.json ffn_fused2_kernel=ffn_fused2_kernel,1048576 qkv_resident_kernel=qkv_resident_kernel attention_long=attention_x3_kernelILi8 search_resident="TileCfg<8, 1, 1, 2>" > /dev/null
+python tools/pmc_traffic_json.py $O/pmc_f $O/pmc_w $O/roofline_traffic.json ffn_fused2_kernel=ffn_fused2_kernel,1048576 qkv_resident_kernel=qkv_resident_kernel attention_6tile=attention_x3_kernelILi6 attention_8tile=attention_x3_kernelILi8 attention_4tile=attention_x3_kernelILi4 search_resident="TileCfg<8, 1, 1, 2>" > /dev/null
 rocprofv3 --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum -d $O/pmc_l2 -- $B --steps 2 --warmup 1 > /dev/null 2> $O/pmc_l2.err && echo pmc-l2-ok
 python tools/pmc_raw.py $O/pmc_l2 > $O/pmc_l2_stream.txt
 rm -rf $O/trace $O/pmc_a $O/pmc_f $O/pmc_w $O/pmc_l2
