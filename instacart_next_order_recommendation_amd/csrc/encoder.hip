@@ -479,7 +479,12 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 half2w a, b;
+#if defined(ICREC_ATT_ABL) && (ICREC_ATT_ABL & 1)  // timing ablation (tools/ffn_bench.hip): no lo plane of P
+                a = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(pt[8 * ks + j], pt[8 * ks + j + 1]));
+                b = a;
+#else
                 split_pair_prescaled(pt[8 * ks + j], pt[8 * ks + j + 1], a, b);
+#endif
                 ph[j] = a[0]; ph[j + 1] = a[1];
                 pl[j] = b[0]; pl[j + 1] = b[1];
             }
@@ -520,7 +525,11 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
                 if (kt < nkt) {
                     f32x16 t = score_tile(kt);
 #pragma unroll
+#if defined(ICREC_ATT_ABL) && (ICREC_ATT_ABL & 2)  // timing ablation: no exponential
+                    for (int e = 0; e < 16; ++e) t[e] = fmaf(t[e], cs, shift);
+#else
                     for (int e = 0; e < 16; ++e) t[e] = __builtin_amdgcn_exp2f(fmaf(t[e], cs, shift));
+#endif
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) ls2 = ls2 + float2w{t[e], t[e + 1]};
                     pv_tile(kt, t, o);

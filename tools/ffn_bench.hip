@@ -218,6 +218,7 @@ int main(int argc, char** argv) {
     }
     return 0;
 #endif
+    if (T0 > 0)  // `tools/_ffn_bench 0`: only the attention lines below
     for (int T : {T0, 131072, 16384}) {
         const double ffn_flops = 4.0 * T * H * I;
         printf("---- T = %d tokens (%d blocks of 64)\n", T, (T + 63) / 64);
@@ -254,6 +255,28 @@ int main(int argc, char** argv) {
         }, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H);
         reinit();
         hipDeviceSynchronize();
+    }
+    {   // attention buckets on uniform-length batches (the product's launch shapes): 4-, 6- and 8-tile kernels
+        const int nseq = 512;
+        const float sl2e = (1.0f / sqrtf(32.0f)) * 1.44269504088896340736f;
+        int* cud; hipMalloc(&cud, (nseq + 1) * 4);
+        auto run = [&](const char* name, int Ls, auto launch) {
+            std::vector<int> cuh(nseq + 1);
+            for (int i = 0; i <= nseq; ++i) cuh[i] = i * Ls;
+            hipMemcpy(cud, cuh.data(), (nseq + 1) * 4, hipMemcpyHostToDevice);
+            fill_float<<<1024, 256>>>(qkv, (size_t)nseq * Ls * 3 * H, 21, 2.0f);
+            timeit(name, launch, 4.0 * nseq * 12 * Ls * Ls * 32);
+        };
+        run("attention_x3<4,4> 512 seq x 110 tok", 110, [&] {
+            hipLaunchKernelGGL((attention_x3_kernel<4, 4, true>), dim3(nseq * 12, 1), dim3(256), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 2);
+        });
+        run("attention_x3<6,6> 512 seq x 176 tok", 176, [&] {
+            hipLaunchKernelGGL((attention_x3_kernel<6, 6, true>), dim3(nseq * 12, 1), dim3(384), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 4);
+        });
+        run("attention_x3<8,8> 512 seq x 230 tok", 230, [&] {
+            hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 6);
+        });
+        hipFree(cud);
     }
     return 0;
 }
