@@ -156,7 +156,9 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
             "l2_stream": {"bytes_per_launch": l2_bytes,
                           "TBps_at_this_launch_time": l2_bytes / (ms * 1e-3) / 1e12 if ms > 0 else None,
                           "note": "L2 -> L1 bytes per launch by construction (one pass over the layer's fragments per 64-token "
-                                  "workgroup); PMC TCP_TCC_READ_REQ of the committed profile agrees (profiles/r03_pmc_l2_stream.txt)"},
+                                  "workgroup); PMC TCP_TCC_READ_REQ of the committed profile agrees (profiles/r03_pmc_l2_stream.txt); "
+                                  "not a wall: the same access pattern without arithmetic streams 23-32 TB/s "
+                                  "(tools/l2_stream.hip, profiles/r03_l2_stream_microbench.txt)"},
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
 

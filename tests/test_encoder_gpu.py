@@ -49,9 +49,10 @@ def test_golden_long_sequences(encoder, golden_encoder):
     assert np.abs(emb - g["hf_embeddings_long"]).max() < EMB_TOL
 
 
-@pytest.mark.parametrize("lens", [[1], [2, 1, 3], [31, 32, 33], [63, 64, 65, 5], [127, 128, 129], [255, 256, 17]])
+@pytest.mark.parametrize("lens", [[1], [2, 1, 3], [31, 32, 33], [63, 64, 65, 5], [127, 128, 129], [255, 256, 17],
+                                  [159, 160, 161], [191, 192, 193, 96], [223, 224, 225]])
 def test_ragged_lengths_vs_oracle(encoder, minilm_weights, lens):
-    """Tile-boundary lengths for every attention variant (1/2/4/8 key tiles), mixed in one batch."""
+    """Tile-boundary lengths for every attention bucket (1 / 2 / 3-4 / 5-6 / 7-8 key tiles), mixed in one batch."""
     from oracle import oracle
 
     rng = np.random.default_rng(sum(lens))
@@ -71,6 +72,20 @@ def test_batch_invariance_bitwise(encoder):
     for s in [0, 3, 5]:
         one = _encode(encoder, ids[cu[s]:cu[s + 1]].copy(), np.array([0, cu[s + 1] - cu[s]], np.int32))
         np.testing.assert_array_equal(one[0], full[s])
+
+
+def test_attention_bucket_boundaries_alone_equal_in_batch(encoder):
+    """Batches put sequences of 5-6 key tiles through the 6-wave kernel, a lone sequence of the same length goes
+    through the 8-tile one (and 3-4 tiles through the 4-tile one either way): the same bits on both sides of every
+    bucket boundary."""
+    lens = [96, 97, 128, 129, 160, 161, 192, 193, 224, 256]
+    rng = np.random.default_rng(5)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ids = rng.integers(0, 30522, size=int(cu[-1])).astype(np.int32)
+    full = _encode(encoder, ids, cu)
+    for s, n in enumerate(lens):
+        one = _encode(encoder, ids[cu[s]:cu[s + 1]].copy(), np.array([0, n], np.int32))
+        np.testing.assert_array_equal(one[0], full[s], err_msg=f"length {n}")
 
 
 def test_small_and_batch_gemm_paths_agree_bitwise(encoder):
