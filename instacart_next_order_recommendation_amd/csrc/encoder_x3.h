@@ -656,7 +656,7 @@ __device__ __forceinline__ void bar_lds() {  // LDS hand-off barrier that leaves
 //   before.  Per output the same chain and the same LayerNorm order as wt_linear_kernel<.., 2> + ln_wt_kernel:
 //   identical bits.
 // VAR (tools/ffn_bench.hip only; the product uses 0), timing ablations: 1 = no GELU, 4 = no in-loop weight loads,
-// 8 = no in-loop LDS fragment reads, 32 = no sched_group_barrier interleave
+// 8 = no in-loop LDS fragment reads, 32 = no sched_group_barrier interleave, 64 = ~16 k idle cycles at the start
 template <int VAR, bool AO = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict__ xh, _Float16* __restrict__ xl,
                                                             int T, int I,
@@ -687,6 +687,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
 
     ICREC_STAMP(0, 0);
     ICREC_STAMP(4, 0);
+    if constexpr ((VAR & 64) != 0) {  // harness: ~16 k idle cycles per workgroup (does time follow cycles or power?)
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
     unsigned lo8 = lane * 8;
     if constexpr (AO) {
         // x1 = LayerNorm(Wo . ctx + bo + x) -> the resident image.

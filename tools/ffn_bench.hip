@@ -253,6 +253,23 @@ int main(int argc, char** argv) {
                                (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
                                (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
         }, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H);
+        if (T == 131072) {  // does the kernel's time follow its cycles (a sleeping workgroup costs time) or the power cap (it does not)?
+            for (int rep = 0; rep < 2; ++rep) {
+                timeit("  [interleaved] layer kernel", [&] {
+                    auto kern = ffn_fused2_kernel<0, true>;
+                    hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                                       (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
+                                       (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
+                }, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H);
+                timeit("  [interleaved] layer kernel + ~16 k idle cycles per workgroup (of ~250 k)", [&] {
+                    auto kern = ffn_fused2_kernel<64, true>;
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+                    hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                                       (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
+                                       (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
+                }, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H);
+            }
+        }
         reinit();
         hipDeviceSynchronize();
     }
