@@ -44,21 +44,40 @@ class RemoteBatcher:
         self._reader: Optional[asyncio.StreamReader] = None
         self._writer: Optional[asyncio.StreamWriter] = None
         self._pending: dict[int, asyncio.Future] = {}
+        self._deadline: dict[int, float] = {}  # rid -> loop time after which the sweeper fails the call
         self._ids = itertools.count(1)
         self._task: Optional[asyncio.Task] = None
         self._on_corpus = on_corpus
         self._lock = asyncio.Lock()
+        self._sweeper: Optional[asyncio.Task] = None
 
     async def start(self) -> None:
         async with self._lock:
             if self._writer is None:
                 self._reader, self._writer = await asyncio.open_unix_connection(self.sock_path, limit=1 << 26)
                 self._task = asyncio.create_task(self._read_loop())
+                if self._sweeper is None:
+                    self._sweeper = asyncio.create_task(self._sweep())
 
     async def stop(self) -> None:
         task, self._task = self._task, None
         if task is not None:
             task.cancel()  # the read loop's `finally` closes the transport and fails what is in flight
+        sw, self._sweeper = self._sweeper, None
+        if sw is not None:
+            sw.cancel()
+
+    async def _sweep(self) -> None:
+        """Fails calls the worker has not answered within call_timeout.  ONE timer for all requests in flight (a
+        per-request asyncio.wait_for costs a timer handle and two callbacks on the hot path)."""
+        while True:
+            await asyncio.sleep(min(1.0, max(self.call_timeout / 4, 0.01)))
+            now = asyncio.get_running_loop().time()
+            for rid in [r for r, d in self._deadline.items() if d <= now]:
+                self._deadline.pop(rid, None)
+                fut = self._pending.pop(rid, None)
+                if fut is not None and not fut.done():
+                    fut.set_exception(WorkerUnavailable(f"GPU worker did not answer within {self.call_timeout:.0f}s"))
 
     @property
     def connected(self) -> bool:
@@ -73,6 +92,7 @@ class RemoteBatcher:
                 if kind == "corpus" and self._on_corpus is not None:
                     self._on_corpus(msg[2])
                 fut = self._pending.pop(rid, None) if rid is not None else None
+                self._deadline.pop(rid, None)
                 if fut is None or fut.done():
                     continue
                 if kind == "ok":
@@ -93,6 +113,7 @@ class RemoteBatcher:
                 if not fut.done():
                     fut.set_exception(WorkerUnavailable("GPU worker connection lost"))
             self._pending.clear()
+            self._deadline.clear()
 
     async def _call(self, msg_tail, kind: str):
         if self._writer is None:
@@ -104,19 +125,18 @@ class RemoteBatcher:
         if writer is None or writer.is_closing():
             raise WorkerUnavailable("GPU worker connection lost")
         rid = next(self._ids)
-        fut = asyncio.get_running_loop().create_future()
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
         self._pending[rid] = fut
+        if kind == "rec":  # a re-index legitimately takes long: no deadline
+            self._deadline[rid] = loop.time() + self.call_timeout
         try:
             writer.write(frame([kind, rid, *msg_tail]))
         except Exception as exc:  # noqa: BLE001 - a transport error must not leave the future registered
             self._pending.pop(rid, None)
+            self._deadline.pop(rid, None)
             raise WorkerUnavailable(f"GPU worker connection lost: {exc}") from exc
-        timeout = self.call_timeout if kind == "rec" else None  # a re-index legitimately takes long
-        try:
-            return await asyncio.wait_for(fut, timeout)
-        except asyncio.TimeoutError:
-            self._pending.pop(rid, None)
-            raise WorkerUnavailable(f"GPU worker did not answer within {timeout:.0f}s") from None
+        return await fut
 
     async def submit(self, query: str, top_k: int, exclude, user_id: Optional[str] = None):
         return await self._call([query, int(top_k), sorted(exclude) if exclude else [], user_id], "rec")
