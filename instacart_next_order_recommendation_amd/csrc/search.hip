@@ -65,7 +65,16 @@ __global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restr
 
 // ---------------------------------------------------------------- score + select
 // candidate queue slots per query between two list merges (more when few queries share the LDS)
+// Candidate queue entries per query: 64 for 32-query tiles, 16 for wider ones.  The resident filter pass takes 32 when
+// the lists are short (k <= 32) and a block walks few rounds (res_qcap): the first rounds of a block offer 16-48
+// candidates per query and would otherwise take two or three offer / merge iterations each - at 49,688 rows x 1,024
+// queries those rounds are most of the kernel (0.274 -> 0.229 ms, same box); blocks that walk thousands of rounds
+// keep 16 (10 M rows: 1 % faster with it).
 template <class Cfg> struct QCap { static constexpr int V = Cfg::BN <= 32 ? 64 : 16; };
+constexpr int RES_QCAP_MAX_ROUNDS = 64;
+__host__ __device__ constexpr int res_qcap(int k, int tiles_per_chunk) {
+    return k <= 32 && tiles_per_chunk <= RES_QCAP_MAX_ROUNDS ? 32 : 16;
+}
 
 // Resident filter pass (PMODE 3): the query tile's two activation planes, [64 queries][384] halfs each, live in LDS
 // for the whole block in the layout of the encoder's fused kernels (768-B rows as three XOR-swizzled 256-B sub-rows).
@@ -81,7 +90,7 @@ struct SearchSmem {
     // dynamic LDS carve (all offsets multiples of 16 B)
     static __host__ __device__ size_t bytes(int k) {
         return GEMM + (size_t)Cfg::BN * (8 /*thr*/ + 4 /*cnt*/) + 16 /*flags*/ +
-               (size_t)Cfg::BN * k * 8 + (size_t)Cfg::BN * QCap<Cfg>::V * 8;
+               (size_t)Cfg::BN * k * 8 + (size_t)Cfg::BN * (MODE == 3 && k <= 32 ? 32 : QCap<Cfg>::V) * 8;
     }
 };
 
@@ -125,25 +134,37 @@ __device__ __forceinline__ void merge_queue(u64* list, const u64* queue, int n, 
 // publishes the new thresholds and clears the queue counters.
 __device__ __forceinline__ void merge_queue2(u64* list, const u64* queue, int qcap, int qa, int na, int qb, int nb, int k,
                                              int lane, u64* thr, int* cnt) {
+    // Two queries per call (k, n <= 32): lanes 0-31 merge query qa, lanes 32-63 query qb.  Lane l holds list entry l and
+    // candidate l of its query; every element's new position is its rank in the union (keys are unique):
+    //   list entry:  l + #{candidates better than it}
+    //   candidate:   #{candidates better than it} + #{list entries better than it}
+    // The candidate counts come from ONE pass over the query's queue in LDS (the 32 lanes of a half read the same
+    // address: a broadcast), the list count from a binary search (the list is sorted, best first, empty slots = 0 last).
+    // (Round 2 broadcast the candidates with v_readlane and counted with ballots: ~5 k cycles per call against ~1 k.)
     const int half = lane >> 5, l = lane & 31;
     const int q = half ? qb : qa, n = half ? nb : na;
     u64* lst = list + (size_t)q * k;
-    const u64 c = l < n ? queue[q * qcap + l] : 0ull;
+    const u64* qp = queue + (size_t)q * qcap;
+    const u64 c = l < n ? qp[l] : 0ull;
     const u64 e0 = l < k ? lst[l] : 0ull;
-    const uint32_t c_lo = (uint32_t)c, c_hi = (uint32_t)(c >> 32);
-    int rc = 0, r0 = 0, lc = 0;
+    int rc = 0, r0 = 0;
     const int nmax = na > nb ? na : nb;
-    for (int i = 0; i < nmax; ++i) {
-        const u64 ca = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)c_hi, i) << 32) |
-                       (u64)(uint32_t)__builtin_amdgcn_readlane((int)c_lo, i);
-        const u64 cb = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)c_hi, 32 + i) << 32) |
-                       (u64)(uint32_t)__builtin_amdgcn_readlane((int)c_lo, 32 + i);
-        const u64 ci = half ? cb : ca;  // 0 past this query's own count: compares false everywhere
-        rc += ci > c;
-        r0 += ci > e0;
-        const unsigned long long m = __ballot(e0 > ci);
-        const int better = half ? __popc((unsigned)(m >> 32)) : __popc((unsigned)m);
-        lc = l == i ? better : lc;
+    for (int i0 = 0; i0 < nmax; i0 += 8) {  // eight reads in flight (one dependent read per candidate is all latency)
+        u64 ci[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ci[u] = qp[i0 + u];  // inside the queue (qcap is 16 or 32, nmax <= qcap), possibly stale
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u64 v = i0 + u < n ? ci[u] : 0ull;  // 0 past this query's own count: compares false everywhere
+            rc += v > c;
+            r0 += v > e0;
+        }
+    }
+    int lc = 0;  // number of list entries better than c = the first index whose entry is not
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int probe = lc + step;
+        if (probe <= k && lst[probe - 1] > c) lc = probe;
     }
     if (n > 0) {
         const int pc = rc + lc, p0 = l + r0;
@@ -190,7 +211,7 @@ __device__ __forceinline__ void r32_mma(f32x16 (&acc)[1][2], const half8& wh, co
 //    PMODE 2 re-stages both operands through LDS for every 128-row tile (two barriers per 64-deep slab).
 // run_flag != NULL: the whole grid exits unless *run_flag != 0 (the exact pass behind a filter pass).
 template <class Cfg, bool EMIT, int PMODE>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
+__global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) void search_kernel(
     const void* __restrict__ P, const void* __restrict__ P2, int64_t N, int K, const void* __restrict__ Qn,
     const void* __restrict__ Q2, int Qpad, int Q, int k, const int32_t* __restrict__ excl_idx,
     const int32_t* __restrict__ excl_off, uint32_t row_base, int n_row_tiles, int tiles_per_chunk, int n_qtiles,
@@ -206,7 +227,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     u64* list = reinterpret_cast<u64*>(flags + 4);
     u64* queue = list + (size_t)Cfg::BN * k;
 
-    constexpr int QCAP = QCap<Cfg>::V;
+    const int QCAP = PMODE == 3 ? res_qcap(k, tiles_per_chunk) : QCap<Cfg>::V;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -214,6 +235,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     const int chunk = bid / n_qtiles, qtile = bid % n_qtiles;
     const int q0 = qtile * Cfg::BN;
 
+    ICREC_STAMP(0, 60);
     for (int i = tid; i < Cfg::BN; i += Cfg::THREADS) { thr[i] = (q0 + i < Q) ? 0ull : ~0ull; cnt[i] = 0; }
     for (int i = tid; i < Cfg::BN * k; i += Cfg::THREADS) list[i] = 0ull;
     if (tid < 4) flags[tid] = 0;
@@ -243,8 +265,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     int xb0[2] = {0, 0};
     const unsigned lo8 = lane * 8;
     if constexpr (PMODE == 3) {
-        static_assert(PMODE != 3 || (Cfg::TM == 1 && Cfg::TN == 2 && Cfg::WAVES_N == 1 && Cfg::WAVES_M == 8),
-                      "resident pass: 8 waves x (1 row tile x 2 query tiles)");
+        static_assert(PMODE != 3 || (Cfg::TM <= 2 && Cfg::TN == 2 && Cfg::WAVES_N == 1 && Cfg::WAVES_M == 8),
+                      "resident pass: 8 waves x (1-2 row tiles x 2 query tiles)");
         const _Float16* qh = static_cast<const _Float16*>(Qn);
         const _Float16* ql = static_cast<const _Float16*>(Q2);
         char* const Xs = smem_raw;
@@ -270,51 +292,59 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
             xb0[tt] = tok * 768 + (((lane >> 5) ^ (tok & 15)) << 4);
         }
         if (t_begin < t_end) {
-            const _Float16* const wp0 = static_cast<const _Float16*>(P) + r32_frag_off(t_begin * 8 + wave, 0, RES_KS);
+            const _Float16* const wp0 = static_cast<const _Float16*>(P) + r32_frag_off((t_begin * 8 + wave) * Cfg::TM, 0, RES_KS);
 #pragma unroll
             for (int d = 0; d < 8; ++d) r32_w_load(rwh[d], rwl[d], wp0, d, lo8);
         }
         __syncthreads();  // queries resident
     }
 
+    ICREC_STAMP(0, 61);
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int64_t row0 = (int64_t)tile * Cfg::BM;
+        if (tile - t_begin < 24) ICREC_STAMP(0, 2 * (tile - t_begin));
         if constexpr (PMODE == 3) {
+            // the wave's TM 32-row tiles of this round, one after the other (fragment tiles (tile * 8 + wave) * TM + i); the
+            // selection below then runs once per round over all of them: its barriers and polls are per round, not per tile
             const char* const Xs = smem_raw;
-            const int rt = tile * 8 + wave;
-            const int rn = tile + 1 < t_end ? rt + 8 : rt;  // past the block's last round: re-read (never consumed)
-            const _Float16* const wp1 = static_cast<const _Float16*>(P) + r32_frag_off(rt, 0, RES_KS);
-            const _Float16* const wpn = static_cast<const _Float16*>(P) + r32_frag_off(rn, 0, RES_KS);
-            f32x16 S[1][2];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int i = 0; i < Cfg::TM; ++i) {
+                const int rt = (tile * 8 + wave) * Cfg::TM + i;
+                // the ring continues into the wave's next tile; past the block's last round: re-read (never consumed)
+                const int rn = i + 1 < Cfg::TM ? rt + 1 : (tile + 1 < t_end ? ((tile + 1) * 8 + wave) * Cfg::TM : rt);
+                const _Float16* const wp1 = static_cast<const _Float16*>(P) + r32_frag_off(rt, 0, RES_KS);
+                const _Float16* const wpn = static_cast<const _Float16*>(P) + r32_frag_off(rn, 0, RES_KS);
+                f32x16 S[1][2];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
-            half8 fh[2][2], fl[2][2];
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb0[tt]);
-                fl[0][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + xb0[tt]);
-            }
+                    for (int e = 0; e < 16; ++e) S[0][tt][e] = 0.0f;
+                half8 fh[2][2], fl[2][2];
 #pragma unroll
-            for (int ks = 0; ks < RES_KS; ++ks) {
-                if (ks + 1 < RES_KS) {
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int pos = (xb0[tt] ^ (((ks + 1) & 7) << 5)) + ((ks + 1) >> 3) * 256;
-                        fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
-                        fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + pos);
-                    }
+                for (int tt = 0; tt < 2; ++tt) {
+                    fh[0][tt] = *reinterpret_cast<const half8*>(Xs + xb0[tt]);
+                    fl[0][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + xb0[tt]);
                 }
-                r32_mma(S, rwh[ks & 7], rwl[ks & 7], fh[ks & 1], fl[ks & 1]);
-                if (ks + 8 < RES_KS) r32_w_load(rwh[ks & 7], rwl[ks & 7], wp1, ks + 8, lo8);
-                else r32_w_load(rwh[ks & 7], rwl[ks & 7], wpn, ks + 8 - RES_KS, lo8);
-                __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+#pragma unroll
+                for (int ks = 0; ks < RES_KS; ++ks) {
+                    if (ks + 1 < RES_KS) {
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const int pos = (xb0[tt] ^ (((ks + 1) & 7) << 5)) + ((ks + 1) >> 3) * 256;
+                            fh[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + pos);
+                            fl[(ks + 1) & 1][tt] = *reinterpret_cast<const half8*>(Xs + RES_XPLANE + pos);
+                        }
+                    }
+                    r32_mma(S, rwh[ks & 7], rwl[ks & 7], fh[ks & 1], fl[ks & 1]);
+                    if (ks + 8 < RES_KS) r32_w_load(rwh[ks & 7], rwl[ks & 7], wp1, ks + 8, lo8);
+                    else r32_w_load(rwh[ks & 7], rwl[ks & 7], wpn, ks + 8 - RES_KS, lo8);
+                    __builtin_amdgcn_sched_barrier(0);  // pin the prefetch to its k-step
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = S[0][j][e] * WT_UNSCALE;
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[0][j][e] = S[0][j][e] * WT_UNSCALE;
         } else if (PMODE == 2) {
             f32x16 a0[Cfg::TM][Cfg::TN], a1[Cfg::TM][Cfg::TN];
             tile_gemm_h<Cfg>(a0, a1, static_cast<const _Float16*>(P), static_cast<const _Float16*>(P2), row0, N,
@@ -343,6 +373,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
                     }
         }
 
+        if (tile - t_begin < 24) ICREC_STAMP(0, 2 * (tile - t_begin) + 1);
         // ---- selection
         // A score is OFFERED (pushed to its query's LDS queue) when it beats the query's threshold.
         //  * warm query (list full): threshold = current k-th best key.  Queues are merged into the
@@ -394,7 +425,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
             offered |= pend;
             if (pass == 0 && lane_cold) flags[2] = 1;
             bool more, wg_cold;
+            [[maybe_unused]] int it_stamp = 0;
             do {
+                if (tile - t_begin == 11 && it_stamp < 6) ICREC_STAMP(0, 30 + 3 * it_stamp);
                 bool lane_pending = false;
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
@@ -427,7 +460,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
                         }
                     }
                 if (lane_pending) flags[round & 1] = 1;
+                if (tile - t_begin == 11 && it_stamp < 6) ICREC_STAMP(0, 31 + 3 * it_stamp);
                 __syncthreads();
+                if (tile - t_begin == 11 && it_stamp < 6) ICREC_STAMP(0, 32 + 3 * it_stamp);
+                ++it_stamp;
                 more = flags[round & 1] != 0;
                 wg_cold = flags[2] != 0;
                 if (tid == 0) flags[(round + 1) & 1] = 0;
@@ -438,7 +474,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
                 static_assert(QPW <= 64, "one polling lane per query");
                 int myc = lane < QPW ? cnt[wave + NW * lane] : 0;
                 myc = myc < QCAP ? myc : QCAP;
-                unsigned long long need = __ballot(myc > 0 && (force || 2 * myc >= QCAP));
+                // merge a queue once it holds 8 candidates (a quarter of the 32-entry queues: the room above absorbs a burst
+                // without a second offer / merge iteration, the early merge keeps the thresholds fresh)
+                const int trig = QCAP >= 32 ? 8 : QCAP / 2;
+                unsigned long long need = __ballot(myc > 0 && (force || myc >= trig));
                 if (QCAP <= 32 && k <= 32) {
                     while (need) {  // two queries per merge call
                         const int ta = __builtin_ctzll(need);
@@ -470,11 +509,13 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
         if (tid == 0) flags[2] = 0;
     }
 
+    ICREC_STAMP(0, 62);
     // sorted partial lists out
     for (int i = tid; i < Cfg::BN * k; i += Cfg::THREADS) {
         const int q = i / k, e = i % k;
         partial[((size_t)chunk * Qpad + q0 + q) * k + e] = list[(size_t)q * k + e];
     }
+    ICREC_STAMP(0, 63);
 }
 
 // ---------------------------------------------------------------- small-batch streaming search
@@ -854,7 +895,7 @@ struct Index {
     _Float16* plane_hi = nullptr;  // ICREC_ROWS_F32_FILTER: f16 hi/lo planes of `rows` for the filter pass
     _Float16* plane_lo = nullptr;
     _Float16* frag = nullptr;      // resident filter pass (dim 384, <= RES_MAX_ROWS rows): the rows as packed fragments
-    int64_t frag_row_tiles = 0;    // 32-row tiles in `frag` (a multiple of 8: whole 256-row rounds)
+    int64_t frag_row_tiles = 0;    // 32-row tiles in `frag` (whole rounds of CfgRes::BM rows)
     int storage = ICREC_ROWS_F32;
     int64_t n_rows = 0;
     int dim = 0;
@@ -1260,7 +1301,7 @@ int icrec_index_create_ex(const float* rows_dev, int64_t n_rows, int32_t dim, in
     const int64_t res_max = res_env && atoll(res_env) > 1 ? atoll(res_env) : RES_MAX_ROWS;
     if (with_planes && dim == 16 * RES_KS && n_rows <= res_max && !(res_env && res_env[0] == '0' && res_env[1] == 0)) {
         // resident filter pass: packed fragments instead of the row-major planes
-        ix->frag_row_tiles = ((n_rows + CfgRes::BM - 1) / CfgRes::BM) * 8;
+        ix->frag_row_tiles = ((n_rows + CfgRes::BM - 1) / CfgRes::BM) * (CfgRes::BM / 32);
         const int64_t n_frag = ix->frag_row_tiles * RES_KS;
         if (hipMalloc(&ix->frag, (size_t)n_frag * 2 * WT_FRAG * sizeof(_Float16)) != hipSuccess) {
             hipFree(ix->rows);
