@@ -210,6 +210,9 @@ __device__ __forceinline__ void r32_mma(f32x16 (&acc)[1][2], const half8& wh, co
 //    across rounds (the next round's first fragments land under the selection): no operand staging barriers at all -
 //    PMODE 2 re-stages both operands through LDS for every 128-row tile (two barriers per 64-deep slab).
 // run_flag != NULL: the whole grid exits unless *run_flag != 0 (the exact pass behind a filter pass).
+#ifndef ICREC_STAMP_ROUND0
+#define ICREC_STAMP_ROUND0 0  // tools/search_stamps.hip: first round of a block whose phases are stamped
+#endif
 template <class Cfg, bool EMIT, int PMODE>
 __global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) void search_kernel(
     const void* __restrict__ P, const void* __restrict__ P2, int64_t N, int K, const void* __restrict__ Qn,
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) 
     ICREC_STAMP(0, 61);
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int64_t row0 = (int64_t)tile * Cfg::BM;
-        if (tile - t_begin < 24) ICREC_STAMP(0, 2 * (tile - t_begin));
+        if (tile - t_begin - ICREC_STAMP_ROUND0 >= 0 && tile - t_begin - ICREC_STAMP_ROUND0 < 24) ICREC_STAMP(0, 2 * (tile - t_begin - ICREC_STAMP_ROUND0));
         if constexpr (PMODE == 3) {
             // the wave's TM 32-row tiles of this round, one after the other (fragment tiles (tile * 8 + wave) * TM + i); the
             // selection below then runs once per round over all of them: its barriers and polls are per round, not per tile
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) 
                     }
         }
 
-        if (tile - t_begin < 24) ICREC_STAMP(0, 2 * (tile - t_begin) + 1);
+        if (tile - t_begin - ICREC_STAMP_ROUND0 >= 0 && tile - t_begin - ICREC_STAMP_ROUND0 < 24) ICREC_STAMP(0, 2 * (tile - t_begin - ICREC_STAMP_ROUND0) + 1);
         // ---- selection
         // A score is OFFERED (pushed to its query's LDS queue) when it beats the query's threshold.
         //  * warm query (list full): threshold = current k-th best key.  Queues are merged into the
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) 
             bool more, wg_cold;
             [[maybe_unused]] int it_stamp = 0;
             do {
-                if (tile - t_begin == 11 && it_stamp < 6) ICREC_STAMP(0, 30 + 3 * it_stamp);
+                if (tile - t_begin - ICREC_STAMP_ROUND0 == 11 && it_stamp < 6) ICREC_STAMP(0, 30 + 3 * it_stamp);
                 bool lane_pending = false;
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
@@ -460,9 +463,9 @@ __global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) 
                         }
                     }
                 if (lane_pending) flags[round & 1] = 1;
-                if (tile - t_begin == 11 && it_stamp < 6) ICREC_STAMP(0, 31 + 3 * it_stamp);
+                if (tile - t_begin - ICREC_STAMP_ROUND0 == 11 && it_stamp < 6) ICREC_STAMP(0, 31 + 3 * it_stamp);
                 __syncthreads();
-                if (tile - t_begin == 11 && it_stamp < 6) ICREC_STAMP(0, 32 + 3 * it_stamp);
+                if (tile - t_begin - ICREC_STAMP_ROUND0 == 11 && it_stamp < 6) ICREC_STAMP(0, 32 + 3 * it_stamp);
                 ++it_stamp;
                 more = flags[round & 1] != 0;
                 wg_cold = flags[2] != 0;

@@ -9,7 +9,8 @@
 
 int main(int argc, char** argv) {
     const int Q = argc > 1 ? atoi(argv[1]) : 1024, k = 20;
-    for (int64_t rows : {8192, 49688}) {
+    const int64_t big = argc > 2 ? atoll(argv[2]) : 49688;
+    for (int64_t rows : {(int64_t)8192, big}) {
         std::vector<float> h((size_t)rows * 384), q((size_t)Q * 384);
         unsigned long long st = 88172645463325252ull;
         auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((double)(st >> 11) / 9007199254740992.0 - 0.5); };
