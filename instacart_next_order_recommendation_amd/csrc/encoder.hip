@@ -411,6 +411,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
             ql[ks] = half8{al[0], al[1], al[2], al[3], bl[0], bl[1], bl[2], bl[3]};
         }
     }
+    ICREC_STAMP(0, 6);  // Q rows arrived and split
     // K/V staging: all of this thread's loads are issued before the first one is consumed
     constexpr int STG = NKT * 32 * 8 / (WAVES * 64);  // = 4 for every bucket (WAVES == NKT)
     static_assert(NKT * 32 * 8 % (WAVES * 64) == 0, "staging: whole rounds");
@@ -424,6 +425,10 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
         kreg[it] = *reinterpret_cast<const f32x4*>(src + H);
         vreg[it] = *reinterpret_cast<const f32x4*>(src + 2 * H);
     }
+#ifdef ICREC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ICREC_STAMP(0, 7);  // K / V rows arrived
+#endif
 #pragma unroll
     for (int it = 0; it < STG; ++it) {
         const int id = tid + it * WAVES * 64;
@@ -518,6 +523,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            ICREC_STAMP(0, 9);  // first score pass (row maxima) done (slot 8 holds the HW id)
             const float shift = fmaf(-mx, cs, 10.0f);
             float2w ls2 = float2w{0.0f, 0.0f};
 #pragma unroll

@@ -183,7 +183,7 @@ int main(int argc, char** argv) {
             for (int rep = 0; rep < 2; ++rep)
                 hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 4);
             hipDeviceSynchronize();
-            dump("attention long (L=200) wave0", nseq * 12, 0, {0, 1, 2, 3, 4, 5});
+            dump("attention long (L=200) wave0: start | Q split | K/V arrived | planes in LDS | barrier | maxima pass | exp + PV pass | barrier | out", nseq * 12, 0, {0, 6, 7, 1, 2, 9, 3, 4, 5});
             {   // per-CU timeline: how much of a CU's span is covered by 0 / 1 / 2 resident workgroups
                 const int nblk = nseq * 12;
                 std::vector<unsigned long long> hs((size_t)nblk * 128);
