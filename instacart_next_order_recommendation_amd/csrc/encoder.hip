@@ -362,10 +362,10 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
     // scales are folded into constants: S' = 256 S, O' = 16384 sum_k p_k V_k, l' = 1024 sum_k p_k, O = O' / (16 l').
     // All splits are the 3-instruction form (mask / subtract / v_cvt_pkrtz pairs).
     //
-    // Long bucket (NKT = 8, RECOMP): the score tiles are computed TWICE - once for the row maximum, once more for the
-    // exponentials, each tile consumed by the PV product as soon as it exists - instead of all eight being held in
-    // 128 registers between the two passes.  Same MFMA chains, same order of every sum: the same bits, 48 more MFMAs
-    // per wave on an idle matrix pipe, and the kernel drops under 128 VGPRs; with the output tile parked on the K
+    // Long buckets (NKT >= 6, RECOMP): the score tiles are computed TWICE - once for the row maximum (on the hi x hi
+    // products alone, see score_tile), once more in full for the exponentials, each tile consumed by the PV product as
+    // soon as it exists - instead of all of them being held in 128 registers between the two passes: 16 more MFMAs per
+    // wave, and the kernel drops under 128 VGPRs; with the output tile parked on the K
     // planes (behind one more barrier) it also drops to 67 KB of LDS - TWO workgroups per CU, so one's staging and
     // barrier phases run under the other's arithmetic.
     constexpr bool RECOMP = NKT >= 6;
@@ -455,7 +455,11 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
 
     // raw scores S' = 256 S of key tile kt for this wave's 32 queries, keys beyond the sequence at -inf (only the one
     // tile that has any pays for the selects: uniform branch)
-    auto score_tile = [&](int kt) {
+    // hi_only (the row-maxima pass of the long buckets): the hi x hi products alone - 2 MFMAs per tile instead of 6.  The
+    // softmax does not care which shift it is given as long as the exponentials stay in range; this approximate maximum
+    // can sit below the true one by at most 2^-10 |q| |k| in score units, the planes of p' = 2^10 p have 2^6 of head room,
+    // and the exponent is clamped for whatever lies beyond (|q| |k| > 2.4e4: two hundred times a BERT head's).
+    auto score_tile = [&](int kt, bool hi_only = false) {
         f32x16 t;
 #pragma unroll
         for (int e = 0; e < 16; ++e) t[e] = 0.0f;
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
             const half8 kh = *reinterpret_cast<const half8*>(Kh + off);
             const half8 kl = *reinterpret_cast<const half8*>(Kl + off);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], t, 0, 0, 0);
+            if (hi_only) continue;
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], t, 0, 0, 0);
         }
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 if (kt < nkt) {
-                    const f32x16 t = score_tile(kt);
+                    const f32x16 t = score_tile(kt, true);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) mx = fmaxf(mx, t[e]);
                 }
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
 #if defined(ICREC_ATT_ABL) && (ICREC_ATT_ABL & 2)  // timing ablation: no exponential
                     for (int e = 0; e < 16; ++e) t[e] = fmaf(t[e], cs, shift);
 #else
-                    for (int e = 0; e < 16; ++e) t[e] = __builtin_amdgcn_exp2f(fmaf(t[e], cs, shift));
+                    for (int e = 0; e < 16; ++e) t[e] = __builtin_amdgcn_exp2f(fminf(fmaf(t[e], cs, shift), 15.9f));
 #endif
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) ls2 = ls2 + float2w{t[e], t[e + 1]};
