@@ -350,6 +350,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo
     }
 }
 
+// ds_read_b64_tr_b16 (gfx950): all 64 lanes must be active; `p` is this lane's Mechanism address (8-byte aligned)
+__device__ __forceinline__ half4 lds_read_tr(const _Float16* p) {
+    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                                         (__attribute__((address_space(3))) fp16x4*)(reinterpret_cast<uintptr_t>(p))));
+}
+
 // nlo: sequences of nlo < nkt <= NKT key tiles belong to this launch (the others' workgroups exit at once)
 template <int NKT, int WAVES, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void attention_x3_kernel(const float* __restrict__ qkv,
@@ -369,12 +376,16 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
     // planes (behind one more barrier) it also drops to 67 KB of LDS - TWO workgroups per CU, so one's staging and
     // barrier phases run under the other's arithmetic.
     constexpr bool RECOMP = NKT >= 6;
-    constexpr int VT = NKT * 32 + 4;  // V^T row stride in halfs (+8 B: the 32 dims land on distinct banks)
     __shared__ __attribute__((aligned(16))) _Float16 Kbuf[2 * NKT * 32 * 32];
     _Float16* const Kh = Kbuf;
     _Float16* const Kl = Kbuf + NKT * 32 * 32;
-    __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VT];
-    __shared__ __attribute__((aligned(16))) _Float16 Vl[32 * VT];
+    // V as it arrives: row-major hi / lo planes [key][32 dims] (64-B rows, one 8-byte store per thread and plane where the
+    // transposed image took four 2-byte ones); the P.V product reads its B operand - 4 consecutive keys of one head
+    // dimension per lane - with the transposing LDS read (ds_read_b64_tr_b16: per 16-lane group a block of 4 keys x 16
+    // dims, lane 4q + p supplying the address of key q, dims 4p..4p+3, lane i receiving dim i of the 4 keys; a 32-lane
+    // half covers 4 rows of 64 B = every bank once).
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[NKT * 32 * 32];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[NKT * 32 * 32];
     __shared__ float Ls[WAVES * 32];
     // Plane output (SPLIT): every wave parks its 32 x 32 output tile (hi | lo) on the K planes once all waves have left
     // them (second barrier) and writes it out 16 B per lane - 4 store instructions instead of 32 two-byte ones.
@@ -437,11 +448,8 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
             half4 khi, klo, vhi, vlo;
             split_act4(kreg[it], khi, klo);
             split_act4(vreg[it], vhi, vlo);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Vh[(c * 4 + i) * VT + key] = vhi[i];
-                Vl[(c * 4 + i) * VT + key] = vlo[i];
-            }
+            *reinterpret_cast<half4*>(Vh + key * 32 + c * 4) = vhi;
+            *reinterpret_cast<half4*>(Vl + key * 32 + c * 4) = vlo;
             const int off = key * 32 + ((((c >> 1) ^ ((key >> 2) & 3)) << 3) | ((c & 1) << 2));
             *reinterpret_cast<half4*>(Kh + off) = khi;
             *reinterpret_cast<half4*>(Kl + off) = klo;
@@ -498,12 +506,13 @@ __global__ __launch_bounds__(WAVES * 64, (NKT >= 6 ? 4 : NKT == 4 ? 3 : 1)) void
                 ph[j] = a[0]; ph[j + 1] = a[1];
                 pl[j] = b[0]; pl[j + 1] = b[1];
             }
-            // this lane's head dim r, keys base .. base+3 and base+8 .. base+11
+            // this lane's head dim r, keys base .. base+3 and base+8 .. base+11: two transposed 4-key x 16-dim blocks per plane
             const int base = kt * 32 + 4 * h + 16 * ks;
-            const half4 v0h = *reinterpret_cast<const half4*>(Vh + r * VT + base);
-            const half4 v1h = *reinterpret_cast<const half4*>(Vh + r * VT + base + 8);
-            const half4 v0l = *reinterpret_cast<const half4*>(Vl + r * VT + base);
-            const half4 v1l = *reinterpret_cast<const half4*>(Vl + r * VT + base + 8);
+            const int tr_at = (base + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const half4 v0h = lds_read_tr(Vh + tr_at);
+            const half4 v1h = lds_read_tr(Vh + tr_at + 8 * 32);
+            const half4 v0l = lds_read_tr(Vl + tr_at);
+            const half4 v1l = lds_read_tr(Vl + tr_at + 8 * 32);
             const half8 vh = {v0h[0], v0h[1], v0h[2], v0h[3], v1h[0], v1h[1], v1h[2], v1h[3]};
             const half8 vl = {v0l[0], v0l[1], v0l[2], v0l[3], v1l[0], v1l[1], v1l[2], v1l[3]};
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, o, 0, 0, 0);
