@@ -290,6 +290,9 @@ int main(int argc, char** argv) {
         run("attention_x3<6,6> 512 seq x 176 tok", 176, [&] {
             hipLaunchKernelGGL((attention_x3_kernel<6, 6, true>), dim3(nseq * 12, 1), dim3(384), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 4);
         });
+        run("attention_x3<1,1> launched over 512 x 12 workgroups that all exit (230-token sequences): dispatch cost", 230, [&] {
+            hipLaunchKernelGGL((attention_x3_kernel<1, 1, true>), dim3(nseq * 12, 1), dim3(64), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 0);
+        });
         run("attention_x3<8,8> 512 seq x 230 tok", 230, [&] {
             hipLaunchKernelGGL((attention_x3_kernel<8, 8, true>), dim3(nseq * 12, 1), dim3(512), 0, 0, qkv, cud, 12, H, sl2e, (float*)nullptr, ch, cl, (const int32_t*)nullptr, 6);
         });
