@@ -697,8 +697,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
         // All eight waves share the work; wave (q, half) owns features q*96 .. +95 of token block `half`:
         //  * it stages its residual rows into the accumulator layout (global -> its private LDS tile -> r);
         //  * the GEMM runs in the producers' form (one 32-feature block x 64 tokens at a time, weight ring 4 k-steps deep,
-        //    the loop of qkv_resident_kernel): producer p takes blocks p and p + 4, consumer q block 8 + q - two waves
-        //    per SIMD, each covering the other's waits;
+        //    the loop of qkv_resident_kernel): producer p takes blocks p, p + 4 and p + 8 while the consumer on its SIMD
+        //    stages its residual rows (a 2 : 1 split with the consumers' rows staged first left the producers waiting);
         //  * the products travel through the context image, dead once every wave has left its K loops: 12 blocks x 2
         //    token blocks x 4 tiles x 1 KB = the 96 KB of the image, each tile in the lane order both sides hold it in
         //    (conflict-free 16-B accesses); every wave picks up the 12 tiles of its (q, half), adds r and takes part in
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
             ffn_x_bases(xb, c, g);
             WFrag w[4][1];
             {
-                const _Float16* const wp0[1] = {Wop + wt_frag_off(PROD ? q : 8 + q, 0, KS1)};
+                const _Float16* const wp0[1] = {Wop + wt_frag_off(q, 0, KS1)};
 #pragma unroll
                 for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp0, d, lo8);
             }
@@ -768,24 +768,23 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                         for (int ti = 0; ti < 2; ++ti) asm volatile("" : "+v"(Y[i][0].t[fi][ti]));
             };
             if constexpr (PROD) {
-                Acc32 S0[2], S1[2];
+                Acc32 S0[2], S1[2], S2[2];
                 ao_block(S0, q, q + 4);
-                ao_block(S1, q + 4, q + 4);
+                ao_block(S1, q + 4, q + 8);
+                ao_block(S2, q + 8, q + 8);
                 ICREC_STAMP(0, 28);
                 wt_res_rows_load(rr, q, tb, xh, xl, m0, T);
                 __syncthreads();  // every wave has left the context image: it takes the products
                 put(S0, q);
                 put(S1, q + 4);
+                put(S2, q + 8);
                 wt_res_rows_acc<false, 1, 0>(Y, rr, q, bo, Hs + LNT_RED + wave * LNT_TILE);  // per-wave private tiles
                 finish_r();
             } else {
                 wt_res_rows_acc<false, 1, 0>(Y, rr, q, bo, Hs + LNT_RED + wave * LNT_TILE);
                 finish_r();
-                Acc32 S2[2];
-                ao_block(S2, 8 + q, 8 + q);
                 ICREC_STAMP(4, 28);
                 __syncthreads();  // every wave has left the context image
-                put(S2, 8 + q);
             }
             __syncthreads();  // products visible
             ICREC_STAMP(0, 29);
