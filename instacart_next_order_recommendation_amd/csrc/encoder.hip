@@ -811,7 +811,7 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
                              const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
     if (T <= X3_SMALL_M) {
         const int nbn = N / 128;
-        hipLaunchKernelGGL((wt_linear_kernel<1, 1, 2, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
+        hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
                            Wp, N, bias, out, oh, ol, nbn);
     } else {
         const int nbn = N / 384;

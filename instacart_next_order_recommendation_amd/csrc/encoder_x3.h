@@ -382,7 +382,7 @@ constexpr int LN_LD = 388;  // floats per staged output row in LDS (+16 B: the 1
 //   EPI 1: erf-GELU (tf:336), result as f16 hi/lo planes   (FFN-up of small batches)
 //   EPI 2: residual + bias (planes rh / rl, row stride N) added to the accumulators after the K loop, out fp32 =
 //          acc * 2^-14: the LayerNorm input of attention-out / FFN-down for small batches (ln_wt_kernel follows)
-// <1, 1, 2, EPI>: the small-batch form (<= 512 tokens and the remainder of a batch): 32-token x 128-feature
+// <1, 1, 4, EPI>: the small-batch form (weights four k-steps ahead) (<= 512 tokens and the remainder of a batch): 32-token x 128-feature
 // workgroups, latency-bound.  <3, 2, 1, EPI>: the 64-token x 384-feature form of the UNFUSED reference chain
 // (ICREC_FUSE=0: tests compare the fused kernels against it bit for bit).
 // Each lane holds 4 consecutive features of one token per register group: 16-B (fp32) / 8-B (planes) stores.

@@ -205,14 +205,15 @@ __device__ unsigned long long g_stamps[1 << 22];
 
 // ---------------------------------------------------------------- whole-K loop of one output tile
 // acc[i][tt] = sum_k W[(nt0 + i) block][k] . X[m0 + tt block][k], K in slabs of 64 (2 k-steps of 32); weight fragments
-// D k-steps ahead in registers (D = 1 or 2), the next activation slab one slab ahead in registers, two LDS stages, one
-// barrier per slab.  `smem`: XRing<TTW>::BYTES.  The fragments of the next (k-step, token block) unit are read from LDS
+// D k-steps ahead in registers (D = 1, 2 or 4: the latency form of single requests keeps four - its few workgroups
+// find a layer's fragments in the Infinity Cache at best, half a microsecond away), the next activation slab one slab
+// ahead in registers, two LDS stages, one barrier per slab.  `smem`: XRing<TTW>::BYTES.  The fragments of the next (k-step, token block) unit are read from LDS
 // under the current unit's MFMAs.
 template <int NTW, int TTW, int D>
 __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16* __restrict__ Wp, int nt0, int K,
                                          const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, int64_t m0,
                                          int64_t T, char* smem) {
-    static_assert(D == 1 || D == 2, "prefetch depth must divide the 2 k-steps of a slab");
+    static_assert(D == 1 || D == 2 || D == 4, "prefetch depth: 1, 2 or 4 k-steps");
     static_assert(TTW == 1 || TTW == 2, "1 or 2 token blocks per wave");
     ICREC_STAMP(0, 0);
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -237,7 +238,8 @@ __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16*
     if (nslab > 2) x_load<TTW>(xa, Xh, Xl, m0, T, K, 2);
     __syncthreads();
     ICREC_STAMP(0, 1);
-    auto slab = [&](int s, u32x4 (&xnext)[2 * TTW]) {  // xnext holds slab s+1 on entry, slab s+3 on exit
+    auto slab = [&](int s, auto parity, u32x4 (&xnext)[2 * TTW]) {  // xnext holds slab s+1 on entry, slab s+3 on exit
+        constexpr int PAR = decltype(parity)::value;  // s & 1: the ring slot of k-step 2 s + j is (2 PAR + j) % D
         const char* st = smem + (s & 1) * XRing<TTW>::STAGE_BYTES;
         XFrag x[2];  // unit u = j * TTW + tt: the next unit's fragments are read under the current one's MFMAs
         x_frag<TTW>(x[0], st, 0, 0, c, g);
@@ -251,13 +253,13 @@ __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16*
                     x_frag<TTW>(x[(u + 1) & 1], st, (u + 1) % TTW, (u + 1) / TTW, c, g);
                     __builtin_amdgcn_sched_barrier(0);  // issue the next unit's LDS reads before this unit's MFMAs
                 }
-                if (tt == 0) wt_mma<NTW, TTW, 0>(acc, w[j % D], x[u & 1]);
-                else wt_mma<NTW, TTW, TTW - 1>(acc, w[j % D], x[u & 1]);
+                if (tt == 0) wt_mma<NTW, TTW, 0>(acc, w[(2 * PAR + j) % D], x[u & 1]);
+                else wt_mma<NTW, TTW, TTW - 1>(acc, w[(2 * PAR + j) % D], x[u & 1]);
                 __builtin_amdgcn_sched_barrier(0);  // keep every prefetch in its unit (the scheduler otherwise sinks the loads to their uses)
             }
             int nk = 2 * s + j + D;  // past the end: re-read the last fragment (never consumed) - no branch in the loop body
             nk = nk < KS ? nk : KS - 1;
-            w_load<NTW>(w[j % D], wp, nk, lo8);
+            w_load<NTW>(w[(2 * PAR + j) % D], wp, nk, lo8);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < nslab) {  // slab-granular (uniform) branches; the k-step body above is straight-line code
@@ -268,8 +270,8 @@ __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16*
         if (s < 24) ICREC_STAMP(0, 2 + s);
     };
     for (int s = 0; s < nslab; s += 2) {  // nslab is even (K is a multiple of 128 for every layer of the encoder)
-        slab(s, xb);
-        slab(s + 1, xa);
+        slab(s, std::integral_constant<int, 0>{}, xb);
+        slab(s + 1, std::integral_constant<int, 1>{}, xa);
     }
 }
 
