@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-request (Q=1) latency loop")
     ap.add_argument("--cpu-sample", type=int, default=128, help="queries in the CPU baseline sample")
+    ap.add_argument("--rows-10m", type=int, default=10_000_000,
+                    help="catalog rows of the configs[4] workload / leg (tests pass a small number)")
+    ap.add_argument("--no-10m-leg", action="store_true",
+                    help="skip the configs[4] leg (4,096 queries over the 10 M-row bf16 catalog) the default line carries")
+    ap.add_argument("--no-http", action="store_true", help="skip the /recommend-over-HTTP leg")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 1024 if a.gpus == 1 else max(4096 // a.gpus, 1)
@@ -80,8 +85,9 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
     t0 = time.perf_counter()
     emb = oracle.encode(weights, cfg, ids_s, cu_s)
     t1 = time.perf_counter()
-    oracle.search(emb, catalog, TOP_K, None)
+    o_idx, o_sc = oracle.search(emb, catalog, TOP_K, None)
     t2 = time.perf_counter()
+    _, o_sc21 = oracle.search(emb, catalog, TOP_K + 1, None)  # for the ambiguity rule of the self-check (untimed)
     one = []
     for i in range(5):
         a = time.perf_counter()
@@ -89,7 +95,8 @@ def cpu_baseline(weights, shape, ids, cu, catalog, n_sample: int):
         oracle.search(e1, catalog, TOP_K, None)
         one.append((time.perf_counter() - a) * 1e3)
     total = r["encode_s"] + r["rank_s"]
-    return {"value": n_sample / total, "unit": "queries/s", "cores": r["torch_threads"], "kind": "port:torch",
+    return {"_oracle": {"emb": emb, "idx": o_idx, "score": o_sc, "score21": o_sc21},
+            "value": n_sample / total, "unit": "queries/s", "cores": r["torch_threads"], "kind": "port:torch",
             "single_request_p50_ms": r["single_request_p50_ms"],
             "reference_serving_qps_one_request_at_a_time": 1e3 / r["single_request_p50_ms"],
             "configs0_single_query_vs_1k_products_p50_ms": r["configs0_p50_ms"],
@@ -155,15 +162,74 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
             # every 64-token workgroup pulls the layer's Wo/W1/W2 fragments + its planes through its vector L1
             "l2_stream": {"bytes_per_launch": l2_bytes,
                           "TBps_at_this_launch_time": l2_bytes / (ms * 1e-3) / 1e12 if ms > 0 else None,
-                          "note": "L2 -> L1 bytes per launch by construction (one pass over the layer's fragments per 64-token "
-                                  "workgroup); PMC TCP_TCC_READ_REQ of the committed profile agrees (profiles/r03_pmc_l2_stream.txt); "
-                                  "not a wall: the same access pattern without arithmetic streams 23-32 TB/s "
-                                  "(tools/l2_stream.hip, profiles/r03_l2_stream_microbench.txt)"},
+                          "note": "L2 -> L1 bytes per launch BY CONSTRUCTION (one pass over the layer's fragments + the block's "
+                                  "planes per 64-token workgroup), an upper figure: the PMC count of the committed profile is "
+                                  "lower (TCP_TCC_READ_REQ x 128 B, profiles/README.md has the reconciliation) because "
+                                  "requests that hit in the vector L1 never reach L2; not a wall either way: the same access "
+                                  "pattern without arithmetic streams 23-32 TB/s (tools/l2_stream.hip, "
+                                  "profiles/r03_l2_stream_microbench.txt)"},
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (the bare form the driver uses): start
+    the N ranks as a FRESH child `python -m torch.distributed.run ... bench.py <same arguments>`, relay its output (rank 0's
+    one JSON line) and exit with its code.  Decided before this process imports torch or touches a GPU: the parent only
+    parses arguments, picks a free loopback port and waits."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def http_leg(seconds: float = 3.0) -> dict:
+    """/recommend over HTTP (north_star words the target as "/recommend QPS"; reference surface
+    src/api/routes/recommend.py:84-199, src/api/schemas.py:15-70): tools/http_load.py as a CHILD process — it starts
+    api/serve.py (1 GPU-owner process + 8 FastAPI front-ends on one port) on the synthetic 49,688-product catalog and 4
+    load-generator processes holding 256 keep-alive connections that POST user contexts (top_k 20) back to back.
+    Everything shares this box's CPU quota (16 CPUs on the GPU box: 9 server processes + 4 generators), so the figure is
+    a host-side number; per-request `recommendation_served` log records are off (METRICS_LOG_LEVEL=WARNING).
+    Runs before this process touches the GPU."""
+    import subprocess
+
+    env = dict(os.environ, METRICS_LOG_LEVEL="WARNING", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(ROOT / "tools" / "http_load.py"), "--frontends", "8", "--client-procs", "4",
+           "--clients", "256", "--seconds", str(seconds)]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"http_load exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+        d = json.loads(line[-1])
+    except Exception as exc:  # noqa: BLE001 - the leg must never take the bench line down with it
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    return {"http_qps": d["qps"], "http_p50_ms": d["p50_ms"], "http_p95_ms": d["p95_ms"], "http_p99_ms": d["p99_ms"],
+            "failed": d["requests_failed"], "requests_ok": d["requests_ok"], "seconds": d["seconds"],
+            "frontends": d["frontends"], "load_generator_processes": d["client_procs"], "connections": d["connections"],
+            "cpu_quota": d["cpu_quota"], "server_startup_s": d["server_startup_s"], "top_k": TOP_K,
+            "leg_wall_s": round(time.perf_counter() - t0, 1),
+            "note": "POST /recommend over loopback TCP, HTTP/1.1 keep-alive, through api/serve.py: 1 GPU-owner process "
+                    "(tokenise + micro-batch + the same encode/search calls as `value`) + 8 FastAPI front-ends, driven by 4 "
+                    "generator processes on the same CPU quota; 0 failed is part of the claim; metrics log records off"}
 
 
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    http = None
+    if (args.gpus == 1 and args.workload == "49k7" and not args.no_http and not args.no_latency
+            and "WORLD_SIZE" not in os.environ):
+        http = http_leg()
     import torch
     import torch.distributed as dist
 
@@ -175,8 +241,6 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # ICREC_BENCH_REHEARSAL=1: every rank uses cuda:0 and gloo — lets the N>1 code path be exercised on
     # a one-GPU box (numbers from such a run are meaningless and flagged in the output).
@@ -196,24 +260,30 @@ def main() -> None:
     enc = DeviceEncoder(weights, shape, dev, gemm_mode=args.gemm_mode)
 
     # ---- catalog shard (embedding-level synthetic: clustered unit vectors)
-    n_rows = CATALOG_ROWS if args.workload == "49k7" else 10_000_000
-    bounds = shard_bounds(n_rows, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
-    if args.workload == "49k7":
-        catalog = syn.synthetic_embeddings(n_rows, shape.hidden, seed=1)
-        shard = torch.from_numpy(catalog[lo:hi]).to(dev)
-    else:  # generated on the device per shard: 200 cluster centres + noise (fp32 rows)
-        catalog = None
-        g = torch.Generator(device=dev).manual_seed(1000 + rank)
-        centres = torch.randn(200, shape.hidden, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
-        shard = torch.empty((hi - lo, shape.hidden), device=dev)
-        for s in range(0, hi - lo, 1 << 18):
-            m = min(1 << 18, hi - lo - s)
-            cid = torch.randint(0, 200, (m,), device=dev, generator=g)
-            shard[s:s + m] = centres[cid] + 0.35 * torch.randn(m, shape.hidden, device=dev, generator=g)
+    def make_shard(n_rows: int, generated: bool, storage: str):
+        """-> (HipShardBackend over this rank's rows, lo, hi, host catalog or None).  `generated`: rows drawn on the
+        device per shard (200 cluster centres + noise, fp32 before the index converts them) instead of the host array."""
+        bounds = shard_bounds(n_rows, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        if not generated:
+            catalog = syn.synthetic_embeddings(n_rows, shape.hidden, seed=1)
+            shard = torch.from_numpy(catalog[lo:hi]).to(dev)
+        else:
+            catalog = None
+            g = torch.Generator(device=dev).manual_seed(1000 + rank)
+            centres = torch.randn(200, shape.hidden, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+            shard = torch.empty((hi - lo, shape.hidden), device=dev)
+            for s in range(0, hi - lo, 1 << 18):
+                m = min(1 << 18, hi - lo - s)
+                cid = torch.randint(0, 200, (m,), device=dev, generator=g)
+                shard[s:s + m] = centres[cid] + 0.35 * torch.randn(m, shape.hidden, device=dev, generator=g)
+        backend = HipShardBackend(shard, lo, dev, storage=storage)
+        del shard
+        return backend, lo, hi, catalog
+
+    n_rows = CATALOG_ROWS if args.workload == "49k7" else args.rows_10m
     row_storage = args.catalog_rows or ("f32+filter" if args.workload == "49k7" else "bf16+filter")
-    backend = HipShardBackend(shard, lo, dev, storage=row_storage)
-    del shard
+    backend, lo, hi, catalog = make_shard(n_rows, args.workload != "49k7", row_storage)
     # N > 1: the exchange runs inside libicrec (icrec_search_sharded: two ncclAllGathers on the step's stream);
     # torch.distributed only carries the 128-byte rendezvous id, the barrier and the max-over-ranks of the clock
     comm, comm_note = None, None
@@ -248,20 +318,25 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(search):
+    def measure(search, batch=None, steps=None, warmup=None, verify=True):
         """W warm-up steps, then exactly K timed steps between two barriers; N > 1: max over ranks and the check of the
-        exchange.  -> (elapsed seconds, last idx, last scores, timer readings, exchange_verified or None)"""
-        def step():
-            enc.encode_packed(ids_d, cu_d, max_len, out=emb)
-            return search.search(emb, TOP_K)
+        exchange.  `batch` = (ids, cu_seqlens, max_len, out) on the device (default: the step's own batch).
+        -> (elapsed seconds, last idx, last scores, timer readings, exchange_verified or None)"""
+        b_ids, b_cu, b_max, b_emb = batch if batch is not None else (ids_d, cu_d, max_len, emb)
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
 
-        for _ in range(args.warmup):
+        def step():
+            enc.encode_packed(b_ids, b_cu, b_max, out=b_emb)
+            return search.search(b_emb, TOP_K)
+
+        for _ in range(warmup):
             step()
         barrier()
         _native.timing_reset()
         _native.timing_enable(True)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             idx, sc = step()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -269,27 +344,40 @@ def main() -> None:
         timers = (_native.timing_query(1), _native.timing_query(2), _native.timing_query(3), _native.timing_query(0))
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            if dist.get_backend() == "gloo":
+                t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
         # ---- N > 1: the exchange validates itself.  Every rank searches a 64-query sample of the gathered batch against
         # a replicated, UNSHARDED copy of the catalog and compares with what the sharded step just returned for those
         # queries: a rank-major layout slip in either all-gather would still produce a plausible QPS, not equal bits.
+        # The same sample then goes through the exclusion exchange (icrec_search_sharded_excl: two more all-gathers and
+        # the device-side CSR rebuild): every LOCAL query excludes its own three best rows (global numbers, mostly on
+        # other ranks' shards), and the gathered result must equal the unsharded search with the gathered lists.
         verified = None
-        if world > 1 and args.workload == "49k7":
+        if verify and world > 1 and args.workload == "49k7":
             from instacart_next_order_recommendation_amd.search import DeviceIndex
 
-            q_all = search.gather_queries(emb)  # torch.distributed all-gather: independent of the library's own
+            q_all = search.gather_queries(b_emb)  # torch.distributed all-gather: independent of the library's own
             n_all = int(q_all.shape[0])
+            n_loc = int(b_emb.shape[0])
             sample = torch.linspace(0, n_all - 1, steps=min(64, n_all), device=dev).round().long().unique()
             full = DeviceIndex(torch.from_numpy(catalog).to(dev), dev, storage="f32")
             ref_idx, ref_sc = full.search(q_all[sample], TOP_K)
             same = bool(torch.equal(ref_idx, idx[sample]) and torch.equal(ref_sc, sc[sample])) and idx.shape[0] == n_all
-            flag = torch.tensor([1 if same else 0], device=dev)
+            mine = idx[rank * n_loc:(rank + 1) * n_loc, :3].cpu().tolist()  # this rank's own queries, gathered order
+            excl_local = [row if (i % 5) else [] for i, row in enumerate(mine)]  # every fifth list empty
+            xi, xs = search.search(b_emb, TOP_K, exclude_local=excl_local, excl_cap=n_loc * 4)
+            all_top3 = idx[:, :3].cpu().tolist()
+            excl_all = [all_top3[g] if ((g % n_loc) % 5) else [] for g in sample.cpu().tolist()]
+            rxi, rxs = full.search(q_all[sample], TOP_K, excl_all)
+            same_excl = bool(torch.equal(rxi, xi[sample]) and torch.equal(rxs, xs[sample]))
+            flag = torch.tensor([1 if same else 0, 1 if same_excl else 0], device=dev)
             if dist.get_backend() == "gloo":
                 flag = flag.cpu()
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # the same verdict on every rank
-            verified = bool(int(flag.item()) == 1)
+            verified = bool(int(flag[0].item()) == 1 and int(flag[1].item()) == 1)
             full.close()
         return elapsed, idx, sc, timers, verified
 
@@ -307,6 +395,43 @@ def main() -> None:
     if exchange_verified is False:
         raise SystemExit(f"rank {rank}: sharded result differs from the unsharded search on the 64-query sample")
     (ffn_ms, ffn_n), (enc_ms, _), (srch_ms, _), (skern_ms, _) = timers
+    n_keep = min(args.cpu_sample, args.batch)  # the timed step's own outputs, kept for the oracle check at the end
+    kept = (emb[:n_keep].cpu().numpy(), idx[:n_keep].cpu().numpy(), sc[:n_keep].cpu().numpy())
+
+    # ---- BASELINE configs[4] beside it, in the same line at every N: 4,096 user contexts per step in total (4,096 / N
+    # encoded per GPU) against a 10 M x 384 bf16 catalog (+ filter fragments) row-sharded N ways, generated on the device
+    # per shard.  north_star's ">= 6x at 8 GPUs on a 10M-row catalog" is the ratio of this leg's `qps` at N = 8 to its
+    # value at N = 1 (strong scaling: the total work per step does not change with N).
+    leg_10m = None
+    if args.workload == "49k7" and not args.no_10m_leg and not (world == 1 and args.no_latency):
+        q_total = 4096 - 4096 % world
+        per_rank = q_total // world
+        be10, lo10, hi10, _ = make_shard(args.rows_10m, True, "bf16+filter")
+        search10 = ShardedSearch(be10, lo10, hi10, comm=comm)
+        ids10_h, cu10_h = syn.synthetic_token_batch(per_rank, seed=4321 + rank)
+        batch10 = (torch.from_numpy(ids10_h).to(dev), torch.from_numpy(cu10_h).to(dev), int(np.diff(cu10_h).max()),
+                   torch.empty((per_rank, shape.hidden), device=dev))
+        steps10, warm10 = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        el10, idx10, sc10, tm10, _ = measure(search10, batch10, steps10, warm10, verify=False)
+        # size-independent properties of the result (the oracle cannot score 10 M rows in bench time): every list sorted
+        # (score descending, lower row first on ties), rows inside the catalog, no row twice
+        s_h, i_h = sc10[:256].cpu().numpy(), idx10[:256].cpu().numpy()
+        d_s = np.diff(s_h, axis=1)
+        props_ok = bool(idx10.shape[0] == q_total and (d_s <= 0).all() and ((d_s < 0) | (np.diff(i_h, axis=1) > 0)).all()
+                        and (i_h >= 0).all() and (i_h < args.rows_10m).all()
+                        and all(len(set(r.tolist())) == TOP_K for r in i_h))
+        leg_10m = {"qps": q_total * steps10 / el10, "ms_per_step": el10 / steps10 * 1e3, "queries_per_step": q_total,
+                   "contexts_encoded_per_gpu": per_rank, "tokens_per_gpu_per_step": int(cu10_h[-1]),
+                   "catalog_rows": args.rows_10m, "rows_per_gpu": hi10 - lo10, "catalog_row_storage": "bf16+filter",
+                   "steps": steps10, "warmup": warm10, "scaling": "strong",
+                   "encode_ms_per_step": tm10[1][0], "search_ms_per_step": tm10[2][0],
+                   "result_properties_ok": props_ok,
+                   "note": "BASELINE configs[4]: the step of `value` at 4,096 queries in total over a 10 M-row bf16 catalog "
+                           "(+ f16 filter fragments) row-sharded over the GPUs; same kernels, same exchange"}
+        if not props_ok:
+            raise SystemExit(f"rank {rank}: 10 M-row leg returned unsorted / out-of-range / duplicate rows")
+        del search10, be10, batch10, idx10, sc10
+        torch.cuda.empty_cache()
 
     # ---- the same step with the product's two-stream encode (DeviceEncoder splits the batch over two HIP
     # streams when it has the host copy of cu_seqlens, as recommend_batch does).  Reported separately: the
@@ -561,8 +686,9 @@ def main() -> None:
             "dtype": "f32" if enc.gemm_mode == "f32" else "f16x3 (f32 operands split into 2 f16 planes, 3 f16 MFMAs per product, f32 accumulate; fp32-level accuracy)",
             "data": "synthetic",
             "config": {
-                "workload": (("BASELINE configs[1]/[2]: encode + cos_sim + top-20 over the 49,688-row catalog, "
-                              f"{args.batch} user contexts per GPU per step") if world == 1 else
+                "workload": (("BASELINE configs[1]/[2] with the token ids of the step's contexts already resident in HBM (from "
+                              "user-context STRINGS in host memory: the key from_strings_pipelined; over HTTP: http_qps): "
+                              f"encode + cos_sim + top-20 over the 49,688-row catalog, {args.batch} user contexts per GPU per step") if world == 1 else
                              (f"BASELINE configs[3]: 49,688-row catalog row-sharded {world}-way, {q_per_step}-query batch "
                               f"({args.batch} contexts encoded per GPU), RCCL all-gather of query embeddings and of "
                               "per-shard partial top-20 lists, merged on every rank")) if args.workload == "49k7" else
@@ -577,9 +703,14 @@ def main() -> None:
                 if world > 1 else "single GPU",
             },
             "rehearsal_not_a_measurement": True if rehearsal else None,
+            "configs4_10m_rows": leg_10m,
+            "http": http, "http_qps": None if not http else http.get("http_qps"),
+            "http_p50_ms": None if not http else http.get("http_p50_ms"),
             "exchange_verified": exchange_verified,
             "exchange_verified_note": None if exchange_verified is None else
-            "every rank: 64-query sample of the gathered batch searched against a replicated unsharded index, indices and scores bit-equal",
+            ("every rank: 64-query sample of the gathered batch searched against a replicated unsharded index, indices and scores "
+             "bit-equal; then again with per-rank exclusion lists (each local query's own top-3 rows, every fifth list empty) "
+             "through the exclusion exchange against the unsharded search with the gathered lists"),
             "exchange": None if world == 1 else ("icrec_search_sharded (RCCL inside libicrec)" if comm is not None else
                                                  (comm_note or "torch.distributed collectives (gloo rehearsal)")),
             "p50_latency_ms_single_request": p50_ms,
@@ -598,11 +729,50 @@ def main() -> None:
             "encode_ms_per_step": enc_ms, "search_ms_per_step": srch_ms, "search_kernel_ms": skern_ms,
             "roofline": roofline(enc.gemm_mode, achieved, ffn_n, ffn_ms, ffn_flops, ffn_tokens),
         }
+        # the whole step against the same roof: SURVEY 8d's algorithmic FLOPs (encoder 21,233,664 L + 9,216 L^2 per
+        # sequence of L tokens, similarity 2 Q N d; split-precision products count once) / step time / the MFMA roof
+        lens = np.diff(cu_h).astype(np.float64)
+        per_tok = n_l * 2.0 * (4 * shape.hidden ** 2 + 2 * shape.hidden * shape.intermediate)
+        step_flops = world * (float((per_tok * lens + n_l * 4.0 * shape.hidden * lens ** 2).sum())) \
+            + 2.0 * q_per_step * n_rows * shape.hidden
+        roof = out["roofline"]["peak"]
+        out["roofline"]["whole_step_flops"] = step_flops
+        out["roofline"]["whole_step_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / (roof * world)
+        out["roofline"]["whole_step_note"] = ("algorithmic encoder + similarity FLOPs of one step (SURVEY 8d) / ms_per_step / "
+                                             "the same MFMA roof (x n_gpus); attention and search run partly on other "
+                                             "instructions, the roof is the one of the dominant kernel")
+        failed_check = None
         if not args.no_cpu_baseline and world == 1 and args.workload == "49k7":
-            out["cpu_baseline"] = cpu_baseline(weights, shape, ids_h, cu_h, catalog, min(args.cpu_sample, args.batch))
+            n_chk = min(args.cpu_sample, args.batch)
+            out["cpu_baseline"] = cpu_baseline(weights, shape, ids_h, cu_h, catalog, n_chk)
+            # ---- the line certifies itself: the embeddings and top-20 lists the TIMED step left in HBM for the first
+            # n_chk contexts, against the C oracle's for the same contexts (computed for the CPU baseline anyway).
+            # Embeddings: the f16x3 bar of the parity tests (5e-6 on unit-norm rows).  Lists: identical rows in
+            # identical order, or the oracle's own top-21 scores of that query hold an adjacent gap below 4e-6 (two rows
+            # that close may legitimately swap when the two embeddings differ by ~2e-7: AMBIGUOUS);
+            # scores within 1e-5 of the oracle's at every position either way.  Anything else fails the run.
+            orc = out["cpu_baseline"].pop("_oracle")
+            g_emb, g_idx, g_sc = kept
+            emb_diff = float(np.abs(g_emb - orc["emb"]).max())
+            same_list = (g_idx == orc["idx"]).all(axis=1)
+            gaps = (orc["score21"][:, :-1] - orc["score21"][:, 1:]).min(axis=1)
+            ambiguous = (~same_list) & (gaps < 4e-6)
+            mismatched = (~same_list) & ~(gaps < 4e-6)
+            sc_diff = float(np.abs(g_sc - orc["score"]).max())
+            ok = bool(emb_diff < 5e-6 and not mismatched.any() and sc_diff < 1e-5)
+            out["checked_vs_oracle"] = {
+                "n": int(n_chk), "max_abs_emb_diff": emb_diff, "top20_identical": int(same_list.sum()),
+                "ambiguous": int(ambiguous.sum()), "mismatched": int(mismatched.sum()), "max_abs_score_diff": sc_diff, "ok": ok,
+                "note": "the timed step's own outputs (emb / idx / score of its first n contexts, read back after the timed "
+                        "region) against oracle/icrec_oracle.c on the same contexts; ambiguous = lists differ and the oracle's "
+                        "top-21 scores of that query hold an adjacent gap < 4e-6; bars: emb 5e-6, scores 1e-5, mismatched 0"}
+            if not ok:
+                failed_check = f"timed step disagrees with the oracle: {out['checked_vs_oracle']}"
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        if failed_check:
+            raise SystemExit(failed_check)
     if world > 1:
         dist.destroy_process_group()
 

@@ -290,7 +290,11 @@ ICREC_API int icrec_search_sharded(icrec_index* idx, icrec_comm* comm, const flo
  *   excl_off_dev   int32[n_local+1] offsets into excl_rows_dev (excl_off[n_local] <= excl_cap)
  *   excl_cap       the padded length of every rank's id buffer: the SAME on every rank (a deployment constant, e.g.
  *                  n_local x the API's per-request limit); 8 * world * excl_cap bytes of workspace
- * Offsets outside [0, excl_cap] are clamped (a malformed list excludes less, never reads out of bounds). */
+ * Offsets are sanitised on the device after the exchange (they arrive from other ranks): clamped to [0, excl_cap] and
+ * made non-decreasing by a running maximum, so a rank's segments are disjoint and hold at most excl_cap ids (a malformed
+ * list excludes less, never reads or writes out of bounds).
+ * Row numbers travel as int32: catalogs of up to 2^31 - 1 rows for THIS exchange (the searches themselves take
+ * row offsets to 4 * 10^9; the reference's catalog has 49,688 rows, BASELINE configs[4] 10^7). */
 ICREC_API size_t icrec_search_sharded_excl_workspace_bytes(const icrec_index* idx, const icrec_comm* comm,
                                                  int32_t n_local_queries, int32_t k, int32_t excl_cap);
 ICREC_API int icrec_search_sharded_excl(icrec_index* idx, icrec_comm* comm, const float* q_local_dev,
@@ -298,6 +302,22 @@ ICREC_API int icrec_search_sharded_excl(icrec_index* idx, icrec_comm* comm, cons
                               const int32_t* excl_rows_dev, const int32_t* excl_off_dev, int32_t excl_cap,
                               int64_t* out_idx_dev, float* out_score_dev,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The device-side step of that exchange on its own, for callers that move the lists with a transport of their own
+ * (torch.distributed, MPI) and for testing the gathered layout without a second GPU: the rank-major buffers exactly
+ * as ncclAllGather lays them down -> the CSR of LOCAL rows icrec_search / icrec_search_partial take for the shard
+ * [row_lo, row_hi).
+ *   off_all_dev   int32[world][n_local+1]   per rank: offsets of its n_local queries into its id buffer (not modified;
+ *                                           sanitised in a workspace copy as described above)
+ *   rows_all_dev  int32[world][excl_cap]    per rank: GLOBAL rows, each query's ascending and unique
+ *   csr_off_dev   int32[world*n_local + 1]  out: offsets for the gathered queries (rank-major)
+ *   csr_idx_dev   int32[world*excl_cap]     out: rows - row_lo of the ids inside the shard, order kept
+ * Workspace: icrec_exclusions_to_shard_csr_workspace_bytes(world, n_local) bytes on `device`. */
+ICREC_API size_t icrec_exclusions_to_shard_csr_workspace_bytes(int32_t world, int32_t n_local_queries);
+ICREC_API int icrec_exclusions_to_shard_csr(const int32_t* off_all_dev, const int32_t* rows_all_dev, int32_t world,
+                                  int32_t n_local_queries, int32_t excl_cap, int64_t row_lo, int64_t row_hi,
+                                  int32_t* csr_off_dev, int32_t* csr_idx_dev,
+                                  void* workspace_dev, size_t workspace_bytes, int device, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Host tokenizer: the WordPiece stage of SentenceTransformer.encode           */

@@ -1,4 +1,6 @@
-"""`python -m instacart_next_order_recommendation_amd` = the reference's `python -m src.inference`."""
+"""`python -m instacart_next_order_recommendation_amd --config configs/inference.yaml` (takes the reference's inference YAML)."""
+import sys
+
 from .cli import main
 
-main()
+sys.exit(main())

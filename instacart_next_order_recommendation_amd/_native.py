@@ -27,6 +27,7 @@ EXPORTS = [
     "icrec_comm_unique_id", "icrec_comm_init", "icrec_comm_destroy", "icrec_comm_rank", "icrec_comm_world",
     "icrec_search_sharded_workspace_bytes", "icrec_search_sharded",
     "icrec_search_sharded_excl_workspace_bytes", "icrec_search_sharded_excl", "icrec_index_row_offset",
+    "icrec_exclusions_to_shard_csr_workspace_bytes", "icrec_exclusions_to_shard_csr",
     "icrec_search_workspace_bytes", "icrec_search", "icrec_search_partial", "icrec_merge_topk",
     "icrec_scores", "icrec_normalize_rows", "icrec_rank_all_workspace_bytes", "icrec_rank_all",
     "icrec_tokenizer_create", "icrec_tokenizer_destroy", "icrec_tokenizer_vocab_size", "icrec_tokenize",
@@ -102,6 +103,8 @@ def lib() -> C.CDLL:
         "icrec_search_sharded": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
         "icrec_search_sharded_excl_workspace_bytes": (sz, [vp, vp, i32, i32, i32]),
         "icrec_search_sharded_excl": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
+        "icrec_exclusions_to_shard_csr_workspace_bytes": (sz, [i32, i32]),
+        "icrec_exclusions_to_shard_csr": (C.c_int, [vp, vp, i32, i32, i32, i64, i64, vp, vp, vp, sz, C.c_int, vp]),
         "icrec_index_row_offset": (i64, [vp]),
         "icrec_index_destroy": (C.c_int, [vp]),
         "icrec_index_rows": (i64, [vp]),

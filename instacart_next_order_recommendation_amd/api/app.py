@@ -148,11 +148,43 @@ async def verify_api_key(request: Request) -> None:
         raise HTTPException(status_code=status.HTTP_401_UNAUTHORIZED, detail="Invalid or missing API key")
 
 
+_lazy_lock: Optional[asyncio.Lock] = None
+
+
 async def get_recommender(request: Request) -> Recommender:  # async: a sync dependency costs a thread-pool hop per request
+    """The app's recommender; loaded ON DEMAND when the lifespan did not run or failed to install one — the reference's
+    fallback (src/api/routes/recommend.py:76-80: `MonitoredRecommender(DEFAULT_MODEL_DIR, DEFAULT_CORPUS_PATH)` inside
+    the dependency).  Same outcome, two differences: the construction (model upload + catalog encode) runs in a worker
+    thread so the event loop keeps answering probes, and concurrent first requests wait for ONE load instead of each
+    starting their own.  A load that fails answers 503 with the reason (the reference lets the exception become a 500)."""
     rec = getattr(request.app.state, "recommender", None)
-    if rec is None:
-        raise HTTPException(status_code=status.HTTP_503_SERVICE_UNAVAILABLE, detail="recommender not loaded")
-    return rec
+    if rec is not None:
+        return rec
+    global _lazy_lock
+    if _lazy_lock is None:
+        _lazy_lock = asyncio.Lock()
+    async with _lazy_lock:
+        rec = getattr(request.app.state, "recommender", None)
+        if rec is not None:
+            return rec
+        logger.warning("Recommender not preloaded; loading on-demand")
+        model_dir = _env_path("MODEL_DIR", "models/two_tower_sbert/final")
+        corpus_path = _env_path("CORPUS_PATH", "processed/p5_mp20_ef0.1/eval_corpus.json")
+        try:
+            sock_path = os.getenv("ICREC_GPU_WORKER_SOCKET")
+            if sock_path:
+                _install_frontend(request.app, sock_path, corpus_path)
+                await request.app.state.batcher.start()
+            else:
+                rec = await asyncio.to_thread(MonitoredRecommender, model_dir=model_dir, corpus_path=corpus_path)
+                _install(request.app, rec, corpus_path)
+        except Exception as exc:  # noqa: BLE001
+            logger.exception("on-demand load failed")
+            raise HTTPException(status_code=status.HTTP_503_SERVICE_UNAVAILABLE,
+                                detail=f"recommender not loaded: {type(exc).__name__}: {exc}") from exc
+        request.app.state.ready = True
+        MODEL_LOADED.set(1)
+        return request.app.state.recommender
 
 
 def _eval_queries(app: FastAPI, corpus_path: Path) -> dict[str, str]:

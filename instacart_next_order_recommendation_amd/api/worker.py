@@ -106,10 +106,11 @@ class GpuWorker:
 
 def run(sock_path: str, model_dir, corpus_path, ready=None) -> None:
     logging.basicConfig(level=logging.INFO, format="%(message)s")
-    # The reference logs one `recommendation_served` record per request at INFO (serve_recommendations.py:268-278) -
-    # at one request at a time.  This process answers >10 k requests per second on ONE Python thread: per-request
-    # records are off unless asked for (METRICS_LOG_LEVEL=INFO); last_metrics / the response's `stats` are unaffected.
-    logging.getLogger("recommender.metrics").setLevel(os.getenv("METRICS_LOG_LEVEL", "WARNING").upper())
+    # The reference logs one `recommendation_served` record per request at INFO (serve_recommendations.py:268-278); so
+    # does this process by default, in either launch mode.  At >10 k requests per second on ONE Python thread
+    # the records cost measurable throughput: METRICS_LOG_LEVEL=WARNING turns them off (bench.py's HTTP leg and
+    # tools/http_load.py runs say so where they do); last_metrics / the response's `stats` are unaffected.
+    logging.getLogger("recommender.metrics").setLevel(os.getenv("METRICS_LOG_LEVEL", "INFO").upper())
 
     async def main():
         w = GpuWorker(model_dir, corpus_path)

@@ -119,7 +119,41 @@ static ExclWs excl_ws(const icrec_index* idx, int n_local, int world, int k, int
     return w;
 }
 
-// gathered query g = (rank r, local query i): its ids are rows_all[r][lo .. hi), lo / hi from off_all[r][i], [i + 1]
+// Offsets arrive from other ranks over the all-gather: nothing a rank checks locally covers them.  One workgroup per
+// rank rewrites its row of off_all in place as the running maximum of the offsets clamped to [0, cap]: the sequence
+// is then non-decreasing inside [0, cap], every query's segment [off[i], off[i+1]) is well-formed, the segments of a
+// rank are disjoint and together hold at most cap ids - so excl_fill_kernel can never write past csr_idx[world * cap]
+// whatever the input was (a malformed list excludes less, it never reads or writes out of bounds: icrec.h).
+__global__ __launch_bounds__(1024) void excl_sanitize_kernel(int32_t* __restrict__ off_all, int n_local, int cap) {
+    __shared__ int part[16];
+    __shared__ int carry_s;
+    int32_t* off = off_all + (size_t)blockIdx.x * (n_local + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base <= n_local; base += 1024) {
+        const int i = base + tid;
+        int x = i <= n_local ? off[i] : 0;
+        x = x < 0 ? 0 : (x > cap ? cap : x);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {  // inclusive max-scan inside the wave
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x = x > y ? x : y;
+        }
+        if (lane == 63) part[wave] = x;
+        __syncthreads();
+        int m = carry_s;
+        for (int w = 0; w < wave; ++w) m = m > part[w] ? m : part[w];
+        x = x > m ? x : m;
+        if (i <= n_local) off[i] = x;
+        __syncthreads();
+        if (tid == 1023) carry_s = x;
+        __syncthreads();
+    }
+}
+
+// gathered query g = (rank r, local query i): its ids are rows_all[r][lo .. hi), lo / hi from the sanitised
+// off_all[r][i], [i + 1] (non-decreasing, inside [0, cap])
 __device__ __forceinline__ void excl_segment(const int32_t* __restrict__ off_all, int n_local, int cap, int g, int& r,
                                              int& lo, int& hi) {
     r = g / n_local;
@@ -187,6 +221,20 @@ __global__ __launch_bounds__(256) void excl_fill_kernel(const int32_t* __restric
         const int64_t v = rows_all[(size_t)r * cap + j];
         if (v >= row_lo && v < row_hi) idx[o++] = (int32_t)(v - row_lo);
     }
+}
+
+// gathered (rank-major) lists -> the CSR of THIS shard: sanitise the offsets in place, count, scan, fill
+static int build_local_csr(int32_t* off_all, const int32_t* rows_all, int world, int n_local, int cap, int64_t row_lo,
+                           int64_t row_hi, int32_t* cnt, int32_t* csr_off, int32_t* csr_idx, hipStream_t st) {
+    const int Q = n_local * world;
+    hipLaunchKernelGGL(excl_sanitize_kernel, dim3(world), dim3(1024), 0, st, off_all, n_local, cap);
+    hipLaunchKernelGGL(excl_count_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, (const int32_t*)off_all, rows_all,
+                       n_local, cap, Q, row_lo, row_hi, cnt);
+    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)cnt, Q, csr_off);
+    hipLaunchKernelGGL(excl_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, (const int32_t*)off_all, rows_all,
+                       n_local, cap, Q, row_lo, row_hi, (const int32_t*)csr_off, csr_idx);
+    ICREC_HIP(hipGetLastError());
+    return ICREC_OK;
 }
 
 }  // namespace icrec
@@ -286,6 +334,34 @@ int icrec_search_sharded(icrec_index* idx, icrec_comm* h, const float* q_local_d
     return icrec_merge_topk(merged_from, c->comm ? c->world : 1, Q, k, out_idx_dev, out_score_dev, c->device, stream);
 }
 
+int icrec_exclusions_to_shard_csr(const int32_t* off_all_dev, const int32_t* rows_all_dev, int32_t world, int32_t n_local,
+                                  int32_t excl_cap, int64_t row_lo, int64_t row_hi, int32_t* csr_off_dev,
+                                  int32_t* csr_idx_dev, void* ws, size_t ws_bytes, int device, void* stream) {
+    ICREC_REQUIRE(off_all_dev && rows_all_dev && csr_off_dev && csr_idx_dev, "icrec_exclusions_to_shard_csr: NULL argument");
+    ICREC_REQUIRE(world >= 1 && n_local >= 1 && excl_cap >= 1 && row_hi >= row_lo,
+                  "icrec_exclusions_to_shard_csr: bad world/n_local/excl_cap/rows (%d, %d, %d)", world, n_local, excl_cap);
+    ICREC_REQUIRE((int64_t)n_local * world < (1ll << 31) && (int64_t)excl_cap * world < (1ll << 31),
+                  "icrec_exclusions_to_shard_csr: too many queries / exclusions");
+    const size_t need = icrec_exclusions_to_shard_csr_workspace_bytes(world, n_local);
+    if (!ws || ws_bytes < need) {
+        set_error("icrec_exclusions_to_shard_csr: workspace too small (%zu < %zu)", ws_bytes, need);
+        return ICREC_ENOMEM;
+    }
+    ICREC_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t Q = (size_t)n_local * world;
+    int32_t* off_copy = reinterpret_cast<int32_t*>(ws);
+    int32_t* cnt = off_copy + (((size_t)world * (n_local + 1) + 63) & ~(size_t)63);
+    ICREC_HIP(hipMemcpyAsync(off_copy, off_all_dev, (size_t)world * (n_local + 1) * 4, hipMemcpyDeviceToDevice, st));
+    (void)Q;
+    return build_local_csr(off_copy, rows_all_dev, world, n_local, excl_cap, row_lo, row_hi, cnt, csr_off_dev, csr_idx_dev, st);
+}
+
+size_t icrec_exclusions_to_shard_csr_workspace_bytes(int32_t world, int32_t n_local) {
+    if (world < 1 || n_local < 1) return 0;
+    return ((((size_t)world * (n_local + 1) + 63) & ~(size_t)63) + (size_t)world * n_local) * 4;
+}
+
 size_t icrec_search_sharded_excl_workspace_bytes(const icrec_index* idx, const icrec_comm* h, int32_t n_local, int32_t k,
                                                  int32_t excl_cap) {
     const Comm* c = reinterpret_cast<const Comm*>(h);
@@ -317,23 +393,19 @@ int icrec_search_sharded_excl(icrec_index* idx, icrec_comm* h, const float* q_lo
     int32_t* cnt = reinterpret_cast<int32_t*>(base + w.cnt);
     int32_t* csr_off = reinterpret_cast<int32_t*>(base + w.csr_off);
     int32_t* csr_idx = reinterpret_cast<int32_t*>(base + w.csr_idx);
-    const int32_t* off_use = excl_off_dev;
+    // the offsets always go through the workspace copy: they are sanitised in place (excl_sanitize_kernel)
     const int32_t* rows_use = excl_rows_dev;
     if (c->comm) {
         ICREC_NCCL(g_rccl.AllGather(excl_off_dev, off_all, (size_t)n_local + 1, ncclInt32, c->comm, st));
         ICREC_NCCL(g_rccl.AllGather(excl_rows_dev, rows_all, (size_t)excl_cap, ncclInt32, c->comm, st));
-        off_use = off_all;
         rows_use = rows_all;
+    } else {
+        ICREC_HIP(hipMemcpyAsync(off_all, excl_off_dev, ((size_t)n_local + 1) * 4, hipMemcpyDeviceToDevice, st));
     }
     const int world = c->comm ? c->world : 1;
-    const int Q = n_local * world;
     const int64_t row_lo = icrec_index_row_offset(idx), row_hi = row_lo + icrec_index_rows(idx);
-    hipLaunchKernelGGL(excl_count_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, off_use, rows_use, n_local, excl_cap, Q,
-                       row_lo, row_hi, cnt);
-    hipLaunchKernelGGL(excl_scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)cnt, Q, csr_off);
-    hipLaunchKernelGGL(excl_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, off_use, rows_use, n_local, excl_cap, Q,
-                       row_lo, row_hi, (const int32_t*)csr_off, csr_idx);
-    ICREC_HIP(hipGetLastError());
+    if (int rc = build_local_csr(off_all, rows_use, world, n_local, excl_cap, row_lo, row_hi, cnt, csr_off, csr_idx, st))
+        return rc;
     return icrec_search_sharded(idx, h, q_local_dev, n_local, k, csr_idx, csr_off, out_idx_dev, out_score_dev,
                                 base + w.inner, w.total - w.inner, stream);
 }

@@ -79,12 +79,13 @@ class DeviceIndex:
         _native.check(L.icrec_index_create_ex(_ptr(rows), self.n_rows, self.dim, self.row_offset, self.device.index,
                                               ROW_STORAGE[storage], C.byref(h)), "icrec_index_create_ex")
         self._h = h
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_by_stream: dict[int, torch.Tensor] = {}
 
     def close(self) -> None:
         if getattr(self, "_h", None):
             _native.lib().icrec_index_destroy(self._h)
             self._h = None
+        self._ws_by_stream = {}
 
     def __del__(self):  # pragma: no cover - best effort
         try:
@@ -94,12 +95,19 @@ class DeviceIndex:
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, n_queries: int, k: int) -> torch.Tensor:
+        """Scratch block for one search, ONE PER STREAM: searches issued on different streams (pipeline.py runs batch
+        i's search on a side stream while the caller may use the index from its own stream) never share scratch memory,
+        and a block is only ever allocated, used and dropped on the stream it belongs to, so the caching allocator's
+        stream-ordered reuse is safe when it grows."""
         need = int(_native.lib().icrec_search_workspace_bytes(self._h, n_queries, k))
         if need == 0:
             raise _native.IcrecError(f"bad search shape: n_queries={n_queries}, k={k}")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = int(torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._ws_by_stream.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream.pop(key, None)
+            ws = self._ws_by_stream[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _queries(self, q) -> torch.Tensor:
         q = torch.as_tensor(q)

@@ -39,6 +39,30 @@ def shard_bounds(n_rows: int, world: int) -> list[int]:
     return out
 
 
+def exclusions_to_shard_csr(off_all: torch.Tensor, rows_all: torch.Tensor, row_lo: int, row_hi: int):
+    """The device-side step of the exclusion exchange on its own (icrec_exclusions_to_shard_csr): the rank-major
+    gathered buffers `off_all` int32 [world, n_local + 1] and `rows_all` int32 [world, excl_cap] (GLOBAL rows) ->
+    (csr_off int32 [world * n_local + 1], csr_idx int32 [world * excl_cap]) of LOCAL rows for the shard
+    [row_lo, row_hi), as icrec_search / icrec_search_partial take them."""
+    from . import _native
+
+    if off_all.dtype != torch.int32 or rows_all.dtype != torch.int32 or off_all.dim() != 2 or rows_all.dim() != 2 \
+            or off_all.shape[0] != rows_all.shape[0] or not off_all.is_cuda or rows_all.device != off_all.device:
+        raise ValueError("off_all int32 [world, n_local + 1] and rows_all int32 [world, excl_cap] on one HIP device")
+    dev = off_all.device
+    world, n_local, cap = int(off_all.shape[0]), int(off_all.shape[1]) - 1, int(rows_all.shape[1])
+    L = _native.lib()
+    ws = torch.empty(int(L.icrec_exclusions_to_shard_csr_workspace_bytes(world, n_local)), dtype=torch.uint8, device=dev)
+    csr_off = torch.empty(world * n_local + 1, dtype=torch.int32, device=dev)
+    csr_idx = torch.zeros(world * cap, dtype=torch.int32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _native.check(L.icrec_exclusions_to_shard_csr(P(off_all.contiguous()), P(rows_all.contiguous()), world, n_local, cap,
+                                                  int(row_lo), int(row_hi), P(csr_off), P(csr_idx), P(ws), ws.numel(),
+                                                  dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                  "icrec_exclusions_to_shard_csr")
+    return csr_off, csr_idx
+
+
 class ShardBackend(Protocol):
     def search_partial(self, q: torch.Tensor, k: int, exclude: Optional[Sequence[Iterable[int]]]) -> torch.Tensor: ...
     def merge(self, keys: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]: ...
@@ -159,7 +183,16 @@ class ShardedSearch:
             self.world = comm.world
         else:
             self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_by_stream: dict[int, torch.Tensor] = {}
+
+    def _workspace(self, need: int, device) -> torch.Tensor:
+        """One scratch block per stream (see DeviceIndex._workspace)."""
+        key = int(torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws_by_stream.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws_by_stream.pop(key, None)
+            ws = self._ws_by_stream[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
 
     def _search_native(self, q_local: torch.Tensor, k: int, exclude_global):
         """icrec_search_sharded: all-gather, shard-local search, all-gather, merge — one C call."""
@@ -176,14 +209,13 @@ class ShardedSearch:
         need = int(L.icrec_search_sharded_workspace_bytes(ix._h, self.comm._h, n_local, k))
         if need == 0:
             raise _native.IcrecError(f"bad sharded search shape: n_local={n_local}, k={k}")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=ix.device)
+        ws = self._workspace(need, ix.device)
         idx = torch.empty((Q, k), dtype=torch.int64, device=ix.device)
         sc = torch.empty((Q, k), dtype=torch.float32, device=ix.device)
         P = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
         st = C.c_void_p(torch.cuda.current_stream(ix.device).cuda_stream)
         _native.check(L.icrec_search_sharded(ix._h, self.comm._h, P(q), n_local, k, P(ei), P(eo), P(idx), P(sc),
-                                             P(self._ws), self._ws.numel(), st), "icrec_search_sharded")
+                                             P(ws), ws.numel(), st), "icrec_search_sharded")
         return idx, sc
 
     DEFAULT_EXCL_PER_QUERY = 128  # default id capacity per local query of the exclusion exchange (excl_cap = n_local x this)
@@ -226,14 +258,13 @@ class ShardedSearch:
         need = int(L.icrec_search_sharded_excl_workspace_bytes(ix._h, self.comm._h, n_local, k, cap))
         if need == 0:
             raise _native.IcrecError(f"bad sharded search shape: n_local={n_local}, k={k}, excl_cap={cap}")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=ix.device)
+        ws = self._workspace(need, ix.device)
         idx = torch.empty((Q, k), dtype=torch.int64, device=ix.device)
         sc = torch.empty((Q, k), dtype=torch.float32, device=ix.device)
         P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         st = C.c_void_p(torch.cuda.current_stream(ix.device).cuda_stream)
         _native.check(L.icrec_search_sharded_excl(ix._h, self.comm._h, P(q), n_local, k, P(rows), P(off), cap, P(idx), P(sc),
-                                                  P(self._ws), self._ws.numel(), st), "icrec_search_sharded_excl")
+                                                  P(ws), ws.numel(), st), "icrec_search_sharded_excl")
         return idx, sc
 
     def _gather_local_exclusions(self, exclude_local, n_local: int, excl_cap: Optional[int]):

@@ -177,3 +177,30 @@ def test_micro_batcher_respects_max_batch_and_propagates_errors():
     sizes, errs = asyncio.run(go())
     assert sum(sizes) == 7 and max(sizes) <= 3
     assert all(isinstance(e, RuntimeError) for e in errs)
+
+
+def test_recommender_is_loaded_on_demand_when_not_preloaded(mock_recommender):
+    """The reference's fallback (src/api/routes/recommend.py:76-80): a request that finds no recommender on the app
+    constructs one.  Here the lifespan's recommender is removed behind the app's back; the next /recommend must load
+    one (ONE constructor call even though it is awaited off the event loop) and answer 200."""
+    with patch(f"{APP_MOD}.MonitoredRecommender", return_value=mock_recommender) as ctor:
+        with TestClient(app) as c:
+            assert ctor.call_count == 1
+            app.state.recommender = None
+            app.state.batcher = None
+            assert c.get("/ready").json() == {"status": "not_ready"}
+            r = c.post("/recommend", json={"user_context": "[+7d w4h14] Organic Milk.", "top_k": 3})
+            assert r.status_code == 200 and len(r.json()["recommendations"]) == 3
+            assert ctor.call_count == 2
+            assert c.get("/ready").json() == {"status": "ready"}
+
+
+def test_on_demand_load_failure_is_a_503(mock_recommender):
+    with patch(f"{APP_MOD}.MonitoredRecommender", return_value=mock_recommender) as ctor:
+        with TestClient(app) as c:
+            app.state.recommender = None
+            ctor.side_effect = FileNotFoundError("no such model dir")
+            r = c.post("/recommend", json={"user_context": "x", "top_k": 3})
+            assert r.status_code == 503 and "no such model dir" in r.json()["detail"]
+            ctor.side_effect = None
+            app.state.recommender = mock_recommender

@@ -185,3 +185,131 @@ def test_configs3_sizes_4096_queries():
     assert (d <= 0).all() and ((d < 0) | (np.diff(i_np, axis=1) > 0)).all()
     comm.close()
     fi.close(); ei.close()
+
+
+def _csr_restatement(off_all, rows_all, cap, row_lo, row_hi):
+    """numpy restatement of comm.hip's excl_sanitize / count / scan / fill: offsets clamped to [0, cap] and made
+    non-decreasing by a running maximum, then per gathered query (rank-major) the ids inside [row_lo, row_hi), rebased."""
+    world, n1 = off_all.shape
+    off = np.maximum.accumulate(np.clip(off_all.astype(np.int64), 0, cap), axis=1)
+    csr_off, csr_idx = [0], []
+    for r in range(world):
+        for i in range(n1 - 1):
+            seg = rows_all[r, off[r, i]:off[r, i + 1]].astype(np.int64)
+            seg = seg[(seg >= row_lo) & (seg < row_hi)] - row_lo
+            csr_idx.extend(seg.tolist())
+            csr_off.append(len(csr_idx))
+    return np.asarray(csr_off, np.int32), np.asarray(csr_idx, np.int32)
+
+
+def test_exclusion_exchange_layout_world8_on_one_gpu():
+    """The W > 1 branch of icrec_search_sharded_excl without a second GPU: the device-side step
+    (icrec_exclusions_to_shard_csr = excl_sanitize / count / scan / fill of csrc/comm.hip) on gathered buffers laid out
+    exactly as ncclAllGather lays them down — [8][512 + 1] offsets, [8][cap] ids — at BASELINE configs[3]'s sizes (8
+    ranks x 512 local queries, shard 1 of the 49,688-row catalog), lists incl. empty and cap-full ranks, against a
+    numpy restatement; then MALFORMED offsets (negative, beyond cap, decreasing — ADVICE r3): never out of bounds,
+    equal to the restatement's sanitised reading; and the CSR drives icrec_search to the oracle's result."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.search import DeviceIndex
+    from instacart_next_order_recommendation_amd.sharded import exclusions_to_shard_csr, shard_bounds
+    from oracle import oracle
+
+    dev = torch.device("cuda:0")
+    W, n_local, cap = 8, 512, 512 * 12
+    b = shard_bounds(49_688, W)
+    lo, hi = b[1], b[2]
+    rng = np.random.default_rng(11)
+    off_all = np.zeros((W, n_local + 1), np.int32)
+    rows_all = np.zeros((W, cap), np.int32)
+    lists = []
+    for r in range(W):
+        flat = []
+        for i in range(n_local):
+            if r == 3:          # a rank without any exclusion
+                n = 0
+            elif r == 5:        # a rank that fills its buffer to the last slot
+                n = 12
+            else:
+                n = int(rng.integers(0, 13)) if i % 7 else 0
+            e = sorted(set(rng.integers(0, 49_688, size=n).tolist())) if r != 5 else \
+                sorted(rng.choice(49_688, size=12, replace=False).tolist())
+            lists.append(e)
+            flat.extend(e)
+            off_all[r, i + 1] = len(flat)
+        assert len(flat) <= cap
+        rows_all[r, :len(flat)] = flat
+        rows_all[r, len(flat):] = 7          # padding past the last offset must be ignored
+    assert off_all[5, -1] == cap
+    want_off, want_idx = _csr_restatement(off_all, rows_all, cap, lo, hi)
+    got_off, got_idx = exclusions_to_shard_csr(torch.from_numpy(off_all).to(dev), torch.from_numpy(rows_all).to(dev), lo, hi)
+    np.testing.assert_array_equal(got_off.cpu().numpy(), want_off)
+    np.testing.assert_array_equal(got_idx.cpu().numpy()[:want_off[-1]], want_idx)
+    # the CSR means what the search expects: gathered queries against the shard, a sample against the oracle
+    P = syn.synthetic_embeddings(49_688, 384, seed=1)
+    q = syn.synthetic_embeddings(W * n_local, 384, seed=2)
+    ix = DeviceIndex(torch.from_numpy(P[lo:hi]).to(dev), dev, row_offset=lo)
+    idx = torch.empty((W * n_local, 20), dtype=torch.int64, device=dev)
+    sc = torch.empty((W * n_local, 20), dtype=torch.float32, device=dev)
+    ix.search_into(torch.from_numpy(q).to(dev), 20, got_idx, got_off, idx, sc)
+    sample = [0, 1, 511, 512, 513, 1535, 1536, 2560, 2561, 3071, 4095]
+    wi, ws = oracle.search(q[sample], P[lo:hi], 20, [[v - lo for v in lists[g] if lo <= v < hi] for g in sample], row_offset=lo)
+    np.testing.assert_array_equal(idx[sample].cpu().numpy(), wi)
+    np.testing.assert_array_equal(sc[sample].cpu().numpy(), ws)
+    ix.close()
+    # malformed offsets from "another rank": overlapping full segments, negatives, beyond cap, decreasing runs
+    bad = off_all.copy()
+    bad[0, :5] = [0, cap, 0, cap, 0]
+    bad[1, 1:9] = [-5, 2 * cap, 3, 2, 1, -1, cap + 1, 0]
+    bad[2] = bad[2][::-1]
+    bad[4, -1] = 2**31 - 1
+    want_off, want_idx = _csr_restatement(bad, rows_all, cap, lo, hi)
+    assert want_off[-1] <= W * cap
+    got_off, got_idx = exclusions_to_shard_csr(torch.from_numpy(bad).to(dev), torch.from_numpy(rows_all).to(dev), lo, hi)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got_off.cpu().numpy(), want_off)
+    np.testing.assert_array_equal(got_idx.cpu().numpy()[:want_off[-1]], want_idx)
+
+
+def test_gathered_partial_keys_layout_world8_on_one_gpu():
+    """The W > 1 branch of icrec_search_sharded without a second GPU: keys_all [8, 4096, 20] built from eight
+    icrec_search_partial calls over the eight row shards of the 49,688-row catalog (rank-major, exactly what
+    ncclAllGather of the per-rank [4096, 20] key blocks lays down) -> icrec_merge_topk == the unsharded index, bit
+    for bit on all 4,096 queries, and == the oracle on a sample.  The first and last shards have 6,211 rows each
+    (49,688 = 8 x 6,211)."""
+    import torch
+
+    from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.search import DeviceIndex, merge_topk
+    from instacart_next_order_recommendation_amd.sharded import shard_bounds
+    from oracle import oracle
+
+    dev = torch.device("cuda:0")
+    W, Q, k = 8, 4096, 20
+    P = syn.synthetic_embeddings(49_688, 384, seed=1)
+    q = syn.synthetic_embeddings(Q, 384, seed=2)
+    Pd, qd = torch.from_numpy(P).to(dev), torch.from_numpy(q).to(dev)
+    b = shard_bounds(49_688, W)
+    assert all(b[r + 1] - b[r] == 6211 for r in range(W))
+    rng = np.random.default_rng(3)
+    excl = [sorted(set(rng.integers(0, 49_688, size=int(rng.integers(0, 30))).tolist())) if g % 3 else [] for g in range(Q)]
+    keys_all = torch.empty((W, Q, k), dtype=torch.int64, device=dev)
+    for r in range(W):
+        lo, hi = b[r], b[r + 1]
+        shard = DeviceIndex(Pd[lo:hi], dev, row_offset=lo, storage="f32+filter" if r % 2 else "f32")
+        keys_all[r] = shard.search_partial(qd, k, [[v - lo for v in e if lo <= v < hi] for e in excl])
+        shard.close()
+    idx, sc = merge_topk(keys_all, k)
+    full = DeviceIndex(Pd, dev)
+    fi, fs = full.search(qd, k, excl)
+    assert torch.equal(idx, fi) and torch.equal(sc, fs)
+    sample = [0, 1, 511, 512, 2047, 2048, 4094, 4095]
+    wi, ws = oracle.search(q[sample], P, k, [excl[g] for g in sample])
+    np.testing.assert_array_equal(idx[sample].cpu().numpy(), wi)
+    np.testing.assert_array_equal(sc[sample].cpu().numpy(), ws)
+    # a rank-major slip would not survive: swapping two ranks' blocks changes nothing (the merge is order-free in the
+    # rank axis), but reading the buffer query-major does
+    wrong, _ = merge_topk(keys_all.permute(1, 0, 2).contiguous().view(W, Q, k), k)
+    assert not torch.equal(wrong, fi)
+    full.close()
