@@ -1,7 +1,9 @@
 """Parity at the sizes BASELINE.json's configs are quoted on (the shapes every perf claim rests on).
 
-configs[2]  the bench batch itself: 1,024 contexts / 131,150 tokens, both GEMM modes, a sample of sequences
-            against the oracle (<= 5e-6) and the rest through bit-level batch invariance
+configs[2]  the bench batch itself: 1,024 contexts / 131,150 tokens, both GEMM modes: >= 160 of its sequences (the
+            first 128 — the ones bench.py's own `checked_vs_oracle` covers — plus the extremes and a random draw)
+            against the oracle (<= 5e-6); those same sequences re-encoded as a batch of their own must give the same
+            bits (batch invariance); every row of the full batch a finite unit vector
 configs[1]  the 49,688-product catalog encode, a sample of rows against the oracle
 configs[4]  a 2 M-row bf16 / bf16+filter catalog against oracle.search(storage="bf16") on a query sample,
             and the full 10 M-row catalog through size-independent properties
@@ -27,7 +29,7 @@ def cuda():
 
 @pytest.mark.parametrize("mode", ["f16x3", "f32"])
 def test_bench_batch_encode_vs_oracle(cuda, minilm_weights, mode):
-    """bench.py's step input (synthetic_token_batch(1024, seed=1234)): 16 sampled sequences vs oracle.encode."""
+    """bench.py's step input (synthetic_token_batch(1024, seed=1234)): >= 160 of its 1,024 sequences vs oracle.encode."""
     torch = cuda
     from instacart_next_order_recommendation_amd import synthetic as syn
     from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
@@ -39,7 +41,9 @@ def test_bench_batch_encode_vs_oracle(cuda, minilm_weights, mode):
     emb = enc.encode_packed(torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), int(np.diff(cu).max())).cpu().numpy()
     assert np.isfinite(emb).all() and np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-6
     lens = np.diff(cu)
-    pick = sorted({0, 1023, int(lens.argmin()), int(lens.argmax()), *np.random.default_rng(7).integers(0, 1024, 12).tolist()})
+    pick = sorted({*range(128), 1023, int(lens.argmin()), int(lens.argmax()),
+                   *np.random.default_rng(7).integers(128, 1024, 40).tolist()})
+    assert len(pick) >= 160
     sub_ids = np.concatenate([ids[cu[s]:cu[s + 1]] for s in pick])
     sub_cu = np.concatenate([[0], np.cumsum([lens[s] for s in pick])]).astype(np.int32)
     oracle.set_threads(oracle.usable_cpus())

@@ -239,14 +239,18 @@ def test_cli_runs_demo_query(tmp_path, capsys):
     corpus = tmp_path / "eval_corpus.json"
     corpus.write_text(json.dumps(syn.synthetic_catalog(200)))
     (tmp_path / "eval_queries.json").write_text(json.dumps({"42": "[+1d w2h9] Greek Yogurt, Honey."}))
-    for extra, head in (({}, "No query or eval_query_id"), ({"query": "[+2d w0h8] Oat Milk."}, "Query:"),
-                        ({"eval_query_id": "42"}, "Query (eval_id=42)")):
+    for extra, argv, origin in (({}, [], "built-in demo context"), ({"query": "[+2d w0h8] Oat Milk."}, [], "(config)"),
+                                ({"eval_query_id": "42"}, [], "eval_queries.json[42]"),
+                                ({"query": "ignored"}, ["--query", "[+3d w1h7] Rye Bread."], "(command line)")):
         cfg = tmp_path / "inference.yaml"
         cfg.write_text(yaml.safe_dump({"model_dir": str(model_dir), "corpus": str(corpus), "use_index": False,
                                        "top_k": 3, "corpus_hf_repo": "ignored/offline", **extra}))
-        cli.main(["--config", str(cfg)])
-        out = capsys.readouterr().out
-        assert head in out and "Top-3 recommendations:" in out and out.count("product_id=") == 3
+        assert cli.main(["--config", str(cfg), *argv]) == 0
+        out = capsys.readouterr().out.splitlines()
+        assert origin in out[0] and len(out) == 4 and all("Product:" in ln for ln in out[1:])
+    assert cli.main(["--config", str(cfg), "--json", "--top-k", "2"]) == 0
+    rows = [json.loads(ln) for ln in capsys.readouterr().out.splitlines()]
+    assert [r["rank"] for r in rows] == [1, 2] and set(rows[0]) == {"rank", "product_id", "score", "product_text"}
 
 
 def test_graph_path_ignores_rows_outside_the_sequence(world):

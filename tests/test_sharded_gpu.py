@@ -61,13 +61,23 @@ def test_two_ranks_real_kernels_equal_unsharded(tmp_path):
 
 
 def test_bench_multi_rank_flow_rehearsal():
-    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64"],
-                  {"ICREC_BENCH_REHEARSAL": "1"})
+    """The BARE form the driver uses, `python bench.py --gpus 2 ...` without a launcher: bench.py starts its own two
+    ranks as a fresh child (torch.distributed.run), relays rank 0's line and exits with the child's code.  Rehearsal
+    mode: both ranks on cuda:0, gloo.  The line carries the configs[4] leg (here 300,000 rows instead of 10 M) and the
+    verdict of the exchange check, exclusion exchange included."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICREC_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--rows-10m", "300000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["rehearsal_not_a_measurement"]
     assert d["config"]["contexts_per_gpu_per_step"] == 64
+    assert d["exchange_verified"] is True
+    leg = d["configs4_10m_rows"]
+    assert leg["queries_per_step"] == 4096 and leg["contexts_encoded_per_gpu"] == 2048 and leg["rows_per_gpu"] == 150000
+    assert leg["result_properties_ok"] and leg["qps"] > 0
 
 
 def test_native_rccl_world1_equals_plain_search():
