@@ -715,6 +715,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                          // rows would spill): requested behind the K loops - they finish first and wait anyway.
             if (!PROD) wt_res_rows_load(rr, q, tb, xh, xl, m0, T);
             ffn_x_stage<512>(Xs, ch, cl, m0, T);  // the context planes
+            ICREC_STAMP(0, 44); ICREC_STAMP(4, 44);
             int xb[2][2];
             ffn_x_bases(xb, c, g);
             WFrag w[4][1];
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                 for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp0, d, lo8);
             }
             __syncthreads();  // context planes resident
+            ICREC_STAMP(0, 45); ICREC_STAMP(4, 45);
             // K = 384 of one block; the ring continues into block `nn` (or re-reads this one's last fragments, never consumed)
             auto ao_block = [&](Acc32 (&S)[2], int nt, int nn) {
                 const _Float16* const wp1[1] = {Wop + wt_frag_off(nt, 0, KS1)};
@@ -782,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
                 finish_r();
             } else {
                 wt_res_rows_acc<false, 1, 0>(Y, rr, q, bo, Hs + LNT_RED + wave * LNT_TILE);
+                ICREC_STAMP(4, 46);
                 finish_r();
                 ICREC_STAMP(4, 28);
                 __syncthreads();  // every wave has left the context image

@@ -163,14 +163,17 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         dump("qkv wave0", nb * 3, 0, {0, 1, 2, 3, 4, 5, 6, 7, 30});
         {
-            auto kao = ffn_fused2_kernel<0, true>;
+#ifndef STAMP_VAR
+#define STAMP_VAR 0
+#endif
+            auto kao = ffn_fused2_kernel<STAMP_VAR, true>;
             hipFuncSetAttribute(reinterpret_cast<const void*>(kao), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
             for (int rep = 0; rep < 2; ++rep)
                 hipLaunchKernelGGL(kao, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
                                    (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn, NOQKV);
             hipDeviceSynchronize();
-            dump("AO+ffn2 producer wave0", nb, 0, {0, 28, 29, 31, 1, 2, 3, 4, 5, 26, 27, 30, 43});
-            dump("AO+ffn2 consumer wave4", nb, 1, {0, 28, 29, 31, 1, 2, 3, 4, 5, 27, 30, 43});
+            dump("AO+ffn2 producer wave0", nb, 0, {0, 44, 45, 28, 29, 31, 1, 2, 3, 4, 5, 26, 27, 30, 43});
+            dump("AO+ffn2 consumer wave4", nb, 1, {0, 44, 45, 46, 28, 29, 31, 1, 2, 3, 4, 5, 27, 30, 43});
         }
         reinit();
         {   // attention, long bucket: 512 sequences of 200 tokens
@@ -253,6 +256,52 @@ int main(int argc, char** argv) {
                                (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
                                (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
         }, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H);
+        if (T == 131072 && getenv("ICREC_GAPS")) {
+            // Does the kernel's duration depend on what the chip did in the milliseconds before it?  The layer kernel timed by
+            // events (and its shader clock, stamps build only) when launched back to back, and with the device left idle for
+            // `gap` microseconds before every launch - the situation of a counter-collection pass, which serialises kernels.
+            auto kern = ffn_fused2_kernel<0, true>;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS);
+            auto launch = [&] {
+                hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                                   (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
+                                   (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
+            };
+            hipEvent_t ea, eb;
+            hipEventCreate(&ea); hipEventCreate(&eb);
+            for (int gap_us : {0, 100, 300, 1000, 3000, 10000, 0}) {
+                for (int i = 0; i < 30; ++i) launch();  // the same thermal state in front of every series
+                hipDeviceSynchronize();
+                std::vector<float> ms;
+                for (int rep = 0; rep < 25; ++rep) {
+                    if (gap_us) { hipDeviceSynchronize(); usleep(gap_us); }
+                    hipEventRecord(ea);
+                    launch();
+                    hipEventRecord(eb);
+                    if (gap_us) { hipEventSynchronize(eb); }
+                    else if (rep == 24) hipEventSynchronize(eb);
+                    if (gap_us || rep == 24) { float t; hipEventElapsedTime(&t, ea, eb); ms.push_back(t); }
+                }
+                std::sort(ms.begin(), ms.end());
+                printf("  layer kernel, device idle %5d us before each launch: median %7.1f us  min %7.1f  max %7.1f  (%zu timed)\n", gap_us,
+                       ms[ms.size() / 2] * 1e3, ms.front() * 1e3, ms.back() * 1e3, ms.size());
+            }
+            // duty cycle: the kernel alternating with a sleeping kernel of about its own length
+        }
+        if (T == 131072 && getenv("ICREC_VARS")) {  // round-robin A/B of layer-kernel variants (VAR bits): ICREC_VARS=1
+            std::vector<Cand> cs;
+#define LAYER_CAND(V)                                                                                                     \
+            {                                                                                                             \
+                auto kern = ffn_fused2_kernel<V, true>;                                                                   \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FFN2_LDS); \
+                cs.push_back({"layer kernel VAR=" #V, [=] {                                                              \
+                    hipLaunchKernelGGL(kern, dim3((T + 63) / 64), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f, \
+                                       (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn, \
+                                       (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H); }, {}});                     \
+            }
+            LAYER_CAND(0) LAYER_CAND(64)
+            compare(cs, ffn_flops + 2.0 * T * H * H + 2.0 * T * H * 3 * H, 25);
+        }
         if (T == 131072) {  // does the kernel's time follow its cycles (a sleeping workgroup costs time) or the power cap (it does not)?
             for (int rep = 0; rep < 2; ++rep) {
                 timeit("  [interleaved] layer kernel", [&] {
