@@ -811,6 +811,10 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
                              const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
     if (T <= X3_SMALL_M) {
         const int nbn = N / 128;
+        if (EPI == 2 && K % 256 == 0 && K >= 1024)  // FFN-down: 48 k-steps, a latency chain: weights eight k-steps ahead
+            hipLaunchKernelGGL((wt_linear_kernel<1, 1, 8, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
+                               Wp, N, bias, out, oh, ol, nbn);
+        else
         hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
                            Wp, N, bias, out, oh, ol, nbn);
     } else {
@@ -1016,6 +1020,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     batch_split(e, T, &T_main, &T_tail);
     const bool fuse = e->fuse, side_stream = e->side_stream;
     const bool qkv_res = fuse && H == 384;
+    const bool lnin = fuse && H == 384 && I % 128 == 0;  // small ranges: LayerNorms folded into the consuming GEMMs
     const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
     Encoder::Side* sd = nullptr;
     if (x3 && side_stream && (T_tail || split_att))
@@ -1058,6 +1063,17 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                                        xl + (size_t)r0 * H, Tn, L.Wqkv_p, L.bqkv, qkv + (size_t)r0 * 3 * H, 3 * H);
                     return ICREC_OK;
                 }
+                if (lnin && l > 0 && Tn <= X3_SMALL_M) {
+                    // small ranges: the previous layer's FFN LayerNorm is this kernel's prologue (t1 rows -> planes in LDS
+                    // and, from the workgroups of feature block 0, to xh / xl): one graph node fewer per layer
+                    const LayerW& Lp = e->layers[l - 1];
+                    const int nbn = 3 * H / 128;
+                    hipLaunchKernelGGL((wt_linear_lnin_kernel<0>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
+                                       (const float*)(t1 + (size_t)r0 * H), Tn, Lp.g2, Lp.b2n, c.ln_eps, xh + (size_t)r0 * H,
+                                       xl + (size_t)r0 * H, L.Wqkv_p, 3 * H, L.bqkv, qkv + (size_t)r0 * 3 * H,
+                                       (_Float16*)nullptr, (_Float16*)nullptr, nbn);
+                    return ICREC_OK;
+                }
                 launch_wt_linear<0>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv,
                                     qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
                 return ICREC_OK;
@@ -1083,13 +1099,22 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                 } else {
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
                     launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes
+                    if (lnin && Tn <= X3_SMALL_M) {  // LayerNorm + FFN-up in one node (wt_linear_lnin_kernel)
+                        const int nbn = I / 128;
+                        hipLaunchKernelGGL((wt_linear_lnin_kernel<1>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
+                                           (const float*)t1r, Tn, L.g1, L.b1n, c.ln_eps, xhr, xlr, L.W1_p, I, L.b1,
+                                           (float*)nullptr, hhr, hlr, nbn);
+                    } else {
                     hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 15) / 16), dim3(256), 0, st, t1r, Tn, L.g1, L.b1n,
                                        c.ln_eps, xhr, xlr);
                     {
                         ScopedTimer tm(Tn > X3_SMALL_M ? T_FFN_UP : T_NSLOTS - 1, st);
                         launch_wt_linear<1>(xhr, xlr, Tn, H, L.W1_p, I, L.b1, nullptr, hhr, hlr, st);
                     }
+                    }
                     launch_wt_linear<2>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, xhr, xlr, st);
+                    // the FFN LayerNorm: the prologue of the next layer's QKV projection (qkv_stage) - but for the last layer
+                    if (!(lnin && Tn <= X3_SMALL_M && l + 1 < c.layers))
                     hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 15) / 16), dim3(256), 0, st, t1r, Tn, L.g2, L.b2n,
                                        c.ln_eps, xhr, xlr);
                 }

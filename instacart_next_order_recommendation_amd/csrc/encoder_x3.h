@@ -532,6 +532,155 @@ __device__ __forceinline__ void ffn_x_frag(XFrag& x, const char* Xs, const int (
     }
 }
 
+// ---------------------------------------------------------------- small batches: LayerNorm folded into the consuming GEMM
+// A replayed hipGraph pays ~5 us per node whatever the node does (profiles/r04_single_request_anatomy.txt), and a single
+// request's LayerNorm nodes did 5 us of nothing else.  The two K = 384 GEMMs that CONSUME a LayerNorm's output (FFN-up
+// behind the attention-output LayerNorm, the next layer's QKV projection behind the FFN LayerNorm) read whole token rows
+// anyway, so every workgroup normalises its 32 rows itself: t1 rows (fp32: dense + bias + residual, as the EPI 2 GEMM
+// wrote them) -> ln_wt_kernel's arithmetic, thread for thread (16 threads per token, the same partial sums, the same
+// shuffle tree: identical bits) -> the planes go into a resident LDS image ([32][384] x 2, layout ffn_x_pos) and - from
+// the workgroups of feature block 0 only - to xh / xl, the residual of the next EPI 2 GEMM.  The weight ring's first four
+// k-steps are requested BEFORE the LayerNorm, so the L2 latency of the first fragments runs under it.  K loop: twelve
+// straight-line k-steps off the image, one 32 x 32 block per wave, per output the chain of wt_kloop (same bits as
+// wt_linear_kernel<1, 1, 4, EPI> on ln_wt_kernel's planes).  EPI 0: fp32 out + bias; EPI 1: erf-GELU planes.
+constexpr int LNIN_XPLANE = 32 * 768;
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __restrict__ a, int T,
+                                                                const float* __restrict__ gam,
+                                                                const float* __restrict__ bet, float eps,
+                                                                _Float16* __restrict__ xh, _Float16* __restrict__ xl,
+                                                                const _Float16* __restrict__ Wp, int N,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                _Float16* __restrict__ oh, _Float16* __restrict__ ol,
+                                                                int n_blocks_n) {
+    constexpr int KS1 = 12;
+    __shared__ __attribute__((aligned(16))) char Xs[2 * LNIN_XPLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wq = wave_uniform(tid >> 6), c = lane & 15, g = lane >> 4;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
+    const int64_t m0 = (int64_t)mt * 32;
+    const int nt = nb * 4 + wq;
+    const unsigned lo8 = lane * 8;
+    WFrag w[4][1];
+    const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp1, d, lo8);
+    f32x4 bv[2];
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) bv[fi] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + fi * 16 + 4 * g);
+    // ---- LayerNorm of the block's 32 rows: two passes of 16 tokens, ln_wt_kernel's thread mapping and order
+    {
+        const int slot = tid & 15, q = slot >> 2, gg = slot & 3;
+        const int base = (tid & 63) & ~15;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            int64_t tok = m0 + row;
+            const bool ok = tok < T;
+            tok = ok ? tok : (int64_t)T - 1;
+            f32x4 v[3][2];
+            float part = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    v[i][fi] = *reinterpret_cast<const f32x4*>(a + tok * 384 + q * 96 + i * 32 + fi * 16 + 4 * gg);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) part = part + v[i][fi][j];
+                }
+            auto tree = [&](float p) {
+                p = p + __shfl_xor(p, 1, 64);
+                p = p + __shfl_xor(p, 2, 64);
+                const float p0 = __shfl(p, base, 64), p1 = __shfl(p, base + 4, 64), p2 = __shfl(p, base + 8, 64),
+                            p3 = __shfl(p, base + 12, 64);
+                return ((p0 + p1) + p2) + p3;
+            };
+            const float mean = tree(part) / 384.0f;
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = v[i][fi][j] - mean;
+                        v[i][fi][j] = d;
+                        sq = fmaf(d, d, sq);
+                    }
+            const float var = tree(sq) / 384.0f;
+            const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    const int feat = q * 96 + i * 32 + fi * 16 + 4 * gg;
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + feat);
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + feat);
+                    f32x4 y;
+                    half4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = fmaf(v[i][fi][j] * rstd, gm[j], bt[j]);
+                    split_act4(y, hi, lo);
+                    const int pos = ffn_x_pos(row, feat >> 3) + 8 * ((feat >> 2) & 1);
+                    *reinterpret_cast<half4*>(Xs + pos) = hi;
+                    *reinterpret_cast<half4*>(Xs + LNIN_XPLANE + pos) = lo;
+                    if (nb == 0 && ok) {
+                        *reinterpret_cast<half4*>(xh + tok * 384 + feat) = hi;
+                        *reinterpret_cast<half4*>(xl + tok * 384 + feat) = lo;
+                    }
+                }
+        }
+    }
+    __syncthreads();  // image resident
+    // ---- K = 384 off the image
+    int xb[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) xb[ti] = (ti * 16 + c) * 768 + ((g ^ c) << 4);
+    auto x_frag1 = [&](XFrag& x, int ks) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int pos = (xb[ti] ^ ((ks & 3) << 6)) + (ks >> 2) * 256;
+            x.h[ti] = *reinterpret_cast<const half8*>(Xs + pos);
+            x.l[ti] = *reinterpret_cast<const half8*>(Xs + LNIN_XPLANE + pos);
+        }
+    };
+    Acc32 S;
+    acc_zero(S);
+    XFrag x[2];
+    x_frag1(x[0], 0);
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + 1 < KS1) {
+            x_frag1(x[(ks + 1) & 1], ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wt_mma_block(S, w[ks & 3][0], x[ks & 1]);
+        if (ks + 4 < KS1) w_load<1>(w[ks & 3], wp1, ks + 4, lo8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+        const int feat = nt * 32 + fi * 16 + 4 * g;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int64_t tok = m0 + ti * 16 + c;
+            if (tok < T) {
+                if (EPI == 1) {
+                    half4 hi, lo;
+                    gelu_split4(S.t[fi][ti], bv[fi], hi, lo);
+                    *reinterpret_cast<half4*>(oh + tok * N + feat) = hi;
+                    *reinterpret_cast<half4*>(ol + tok * N + feat) = lo;
+                } else {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(S.t[fi][ti][j], WT_UNSCALE, bv[fi][j]);
+                    *reinterpret_cast<f32x4*>(out + tok * N + feat) = v;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- QKV projection, activation-resident form (large batches)
 // out[T, N] = X . W^T + bias for a block of 64 tokens and ALL N = 1,152 features on the eight waves of a workgroup,
 // built like the producer half of the fused kernel: the block's 64 x 384 activation planes are resident in LDS (96 KB),
@@ -687,6 +836,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
 
     ICREC_STAMP(0, 0);
     ICREC_STAMP(4, 0);
+    ICREC_STAMP_RT(0, 62);
     if constexpr ((VAR & 64) != 0) {  // harness: ~16 k idle cycles per workgroup (does time follow cycles or power?)
         __builtin_amdgcn_s_sleep(127);
         __builtin_amdgcn_s_sleep(127);
@@ -1029,6 +1179,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused2_kernel(_Float16* __restrict
     }
     ICREC_STAMP(0, 43);
     ICREC_STAMP(4, 43);
+    ICREC_STAMP_RT(0, 63);
 }
 
 __global__ __launch_bounds__(512, 2) void qkv_resident_kernel(const _Float16* __restrict__ xh,

@@ -27,21 +27,29 @@ MAX_EXCLUDED = 1024
 
 
 class _Captured:
+    """One captured (token bucket, k) shape.  Every graph node costs ~5 us on this system whatever it does (kernel trace
+    of a replay: profiles/r04_single_request_anatomy.txt), so the request carries no copy nodes at all: the kernels read
+    ids / cu_seqlens / exclusions as VIEWS of the one device buffer the host fills with a single H2D copy, and the last
+    kernel writes the k results straight into pinned host memory (device-accessible at the same address under ROCm's
+    unified addressing) — round 3's graph had four device-to-device and two device-to-host copy nodes around the 47
+    kernels."""
+
     def __init__(self, enc: DeviceEncoder, index: DeviceIndex, bucket: int, k: int):
         dev = enc.device
         self.bucket, self.k = bucket, k
-        self.ids = torch.zeros(bucket, dtype=torch.int32, device=dev)
-        self.cu = torch.tensor([0, bucket], dtype=torch.int32, device=dev)
-        self.excl_idx = torch.zeros(MAX_EXCLUDED, dtype=torch.int32, device=dev)
-        self.excl_off = torch.zeros(2, dtype=torch.int32, device=dev)
-        self.emb = torch.empty((1, enc.shape.hidden), dtype=torch.float32, device=dev)
-        self.out_idx = torch.empty((1, k), dtype=torch.int64, device=dev)
-        self.out_sc = torch.empty((1, k), dtype=torch.float32, device=dev)
-        # pinned staging: [ids (bucket) | cu (2) | excl_off (2) | excl_idx (MAX_EXCLUDED)]
-        self.h_in = torch.zeros(bucket + 4 + MAX_EXCLUDED, dtype=torch.int32).pin_memory()
+        # device staging, one H2D per request: [cu (2) | excl_off (2) | ids (bucket) | excl_idx (MAX_EXCLUDED)]; the views
+        # the kernels read (cu first: 8-byte aligned pairs, ids 16-byte aligned)
+        self.h_in = torch.zeros(4 + bucket + MAX_EXCLUDED, dtype=torch.int32).pin_memory()
         self.d_in = torch.zeros_like(self.h_in, device=dev)
-        self.h_idx = torch.empty((1, k), dtype=torch.int64).pin_memory()
-        self.h_sc = torch.empty((1, k), dtype=torch.float32).pin_memory()
+        self.cu = self.d_in[0:2]
+        self.excl_off = self.d_in[2:4]
+        self.ids = self.d_in[4:4 + bucket]
+        self.excl_idx = self.d_in[4 + bucket:]
+        self.emb = torch.empty((1, enc.shape.hidden), dtype=torch.float32, device=dev)
+        # results: written by icrec_search directly into pinned host memory
+        self.h_idx = torch.full((1, k), -1, dtype=torch.int64).pin_memory()
+        self.h_sc = torch.zeros((1, k), dtype=torch.float32).pin_memory()
+        self.out_idx, self.out_sc = self.h_idx, self.h_sc
 
         # the graph bakes raw pointers: it must own its scratch memory (the encoder's / index's shared
         # workspaces are re-allocated when a later, larger un-captured call needs more room)
@@ -51,10 +59,6 @@ class _Captured:
         P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
         def body_encode():
-            self.ids.copy_(self.d_in[:bucket])
-            self.cu.copy_(self.d_in[bucket:bucket + 2])
-            self.excl_off.copy_(self.d_in[bucket + 2:bucket + 4])
-            self.excl_idx.copy_(self.d_in[bucket + 4:])
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _native.check(L.icrec_encode(enc._h, P(self.ids), P(self.cu), 1, bucket, bucket, P(self.emb),
                                          P(self.enc_ws), self.enc_ws.numel(), st), "icrec_encode")
@@ -132,14 +136,14 @@ class SingleRequestPath:
         if c is None:
             c = self._graphs[(bucket, k)] = _Captured(self.encoder, self.index, bucket, k)
         h = c.h_in
-        h[:n] = torch.as_tensor(ids, dtype=torch.int32)
-        h[n:bucket] = 0
-        h[bucket] = 0
-        h[bucket + 1] = n
-        h[bucket + 2] = 0
-        h[bucket + 3] = len(ex)
+        h[0] = 0
+        h[1] = n
+        h[2] = 0
+        h[3] = len(ex)
+        h[4:4 + n] = torch.as_tensor(ids, dtype=torch.int32)
+        h[4 + n:4 + bucket] = 0
         if ex:
-            h[bucket + 4:bucket + 4 + len(ex)] = torch.as_tensor(ex, dtype=torch.int32)
+            h[4 + bucket:4 + bucket + len(ex)] = torch.as_tensor(ex, dtype=torch.int32)
         stream = torch.cuda.current_stream(self.encoder.device)
         if timed:
             g_enc, g_srch, (e0, e1, e2) = c.timed_graphs()
@@ -152,9 +156,7 @@ class SingleRequestPath:
             e2.record(stream)
         else:
             c.graph.replay()
-        c.h_idx.copy_(c.out_idx, non_blocking=True)
-        c.h_sc.copy_(c.out_sc, non_blocking=True)
-        stream.synchronize()
+        stream.synchronize()  # the last kernel wrote the results into pinned host memory
         if timed:
             return c.h_idx[0].numpy().copy(), c.h_sc[0].numpy().copy(), e0.elapsed_time(e1), e1.elapsed_time(e2)
         return c.h_idx[0].numpy().copy(), c.h_sc[0].numpy().copy()

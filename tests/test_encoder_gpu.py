@@ -217,6 +217,32 @@ def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, 
     ref.close()
 
 
+@pytest.mark.parametrize("lens", [[99], [1], [33, 1, 32, 31, 64, 200], [256, 255]])
+def test_small_batches_with_layernorms_folded_into_the_gemms_bitwise(minilm_weights, monkeypatch, lens):
+    """Up to 512 tokens the two LayerNorms of a layer are the prologues of the GEMMs that consume them
+    (wt_linear_lnin_kernel: FFN-up, the next layer's QKV projection; the last layer's FFN LayerNorm stays a kernel) -
+    11 graph nodes fewer per request.  ICREC_FUSE=0 keeps the separate ln_wt_kernel launches: same arithmetic thread for
+    thread => identical bits; rows of a 32-token block past the end of the batch never reach a real row."""
+    import torch
+
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
+
+    enc = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    monkeypatch.setenv("ICREC_FUSE", "0")
+    ref = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    monkeypatch.delenv("ICREC_FUSE")
+    rng = np.random.default_rng(len(lens))
+    ids = rng.integers(1000, 30000, size=int(np.sum(lens))).astype(np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    assert int(cu[-1]) <= 512
+    args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), int(max(lens)))
+    got = enc.encode_packed(*args).cpu().numpy()
+    want = ref.encode_packed(*args).cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_array_equal(got, want)
+    enc.close(); ref.close()
+
+
 def test_side_stream_changes_nothing(minilm_weights, monkeypatch):
     """A batch of whole 64-token-per-CU rounds + a short remainder: the remainder's small-batch kernels and the short
     attention buckets run on the library's side stream (fork / join by events inside icrec_encode).

@@ -175,6 +175,39 @@ int main(int argc, char** argv) {
             dump("AO+ffn2 producer wave0", nb, 0, {0, 44, 45, 28, 29, 31, 1, 2, 3, 4, 5, 26, 27, 30, 43});
             dump("AO+ffn2 consumer wave4", nb, 1, {0, 44, 45, 46, 28, 29, 31, 1, 2, 3, 4, 5, 27, 30, 43});
         }
+        if (T == 131072) {
+            // In-kernel clock of the LAYER kernel (guide, DVFS item 6): d(s_memtime) / d(s_memrealtime) x 100 MHz per workgroup,
+            // median over the workgroups of one launch that follows >= 2 s of back-to-back launches; the launch's wall time by
+            // events beside it, and the workgroup life in both units.
+            auto kl = ffn_fused2_kernel<0, true>;
+            auto launch = [&] {
+                hipLaunchKernelGGL(kl, dim3(nb), dim3(512), FFN2_LDS, 0, xh, xl, T, I, W1p, b1, W2p, b2, g, bn, 1e-12f,
+                                   (const _Float16*)ch, (const _Float16*)cl, (const _Float16*)Wop, (const float*)b2, (const float*)g, (const float*)bn,
+                                   (const _Float16*)Wqp, (const float*)bq, qkv, 3 * H);
+            };
+            for (int rep = 0; rep < 1800; ++rep) launch();  // ~2.1 s
+            hipEvent_t ea, eb;
+            hipEventCreate(&ea); hipEventCreate(&eb);
+            hipEventRecord(ea);
+            launch();
+            hipEventRecord(eb);
+            hipEventSynchronize(eb);
+            float ms; hipEventElapsedTime(&ms, ea, eb);
+            std::vector<unsigned long long> hs((size_t)nb * 128);
+            hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(g_stamps), hs.size() * 8);
+            std::vector<double> clk, life_c, life_us;
+            for (int b = 0; b < nb; ++b) {
+                const double dc = (double)(hs[(size_t)b * 128 + 43] - hs[(size_t)b * 128 + 0]);
+                const double dr = (double)(hs[(size_t)b * 128 + 63] - hs[(size_t)b * 128 + 62]);
+                if (dr > 0) { clk.push_back(dc / dr * 0.1); life_c.push_back(dc); life_us.push_back(dr * 0.01); }
+            }
+            std::sort(clk.begin(), clk.end()); std::sort(life_c.begin(), life_c.end()); std::sort(life_us.begin(), life_us.end());
+            double sum_us = 0; for (double v : life_us) sum_us += v;
+            printf("layer kernel after 2 s of back-to-back launches: %.1f us by events; in-kernel clock median %.3f GHz (p10 %.3f, p90 %.3f); "
+                   "workgroup life median %.0f shader cycles = %.1f us; sum of workgroup lives / 256 CUs = %.1f us\n", ms * 1e3,
+                   clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10], life_c[life_c.size() / 2],
+                   life_us[life_us.size() / 2], sum_us / 256);
+        }
         reinit();
         {   // attention, long bucket: 512 sequences of 200 tokens
             const int nseq = 512, Ls = 200;
