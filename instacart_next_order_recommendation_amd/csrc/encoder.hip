@@ -811,10 +811,6 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
                              const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
     if (T <= X3_SMALL_M) {
         const int nbn = N / 128;
-        if (EPI == 2 && K % 256 == 0 && K >= 1024)  // FFN-down: 48 k-steps, a latency chain: weights eight k-steps ahead
-            hipLaunchKernelGGL((wt_linear_kernel<1, 1, 8, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
-                               Wp, N, bias, out, oh, ol, nbn);
-        else
         hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
                            Wp, N, bias, out, oh, ol, nbn);
     } else {

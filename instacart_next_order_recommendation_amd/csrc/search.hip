@@ -27,10 +27,7 @@ __device__ __forceinline__ uint16_t bf16_rne(float v) {
 template <bool OUT16>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, void* __restrict__ outv,
                                                              int64_t n_rows, int64_t n_out_rows, int dim, float eps,
-                                                             int tr_cols = 0, int* __restrict__ zero_me = nullptr) {
-    // the arrival counter of the streaming search launched behind this kernel (its last workgroup merges the partial
-    // lists): zeroed HERE, by the node in front of it, so that nothing depends on what the caller's workspace held
-    if (zero_me != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;
+                                                             int tr_cols = 0) {
     float* out = static_cast<float*>(outv);
     uint16_t* out16 = static_cast<uint16_t*>(outv);
     const int lane = threadIdx.x & 63;
@@ -574,13 +571,11 @@ __device__ __forceinline__ void stream_load_slab(v4f (&pre)[8], const char* __re
     }
 }
 
-constexpr int STREAM_FUSED_MERGE_KEYS = 16 * ST_ROWS;  // keys per query the last workgroup of the streaming search merges itself
 template <int NQ, bool P16>
 __global__ __launch_bounds__(ST_ROWS, 2) void stream_search_kernel(
     const void* __restrict__ P, int64_t N, int K, const float* __restrict__ Qn /* [K][NQ], zero-padded columns */, int Q,
     int k, const int32_t* __restrict__ excl_idx, const int32_t* __restrict__ excl_off, uint32_t row_base, int n_row_tiles,
-    int tiles_per_chunk, u64* __restrict__ partial, int* __restrict__ arrivals = nullptr,
-    int64_t* __restrict__ out_idx = nullptr, float* __restrict__ out_score = nullptr, u64* __restrict__ out_keys = nullptr) {
+    int tiles_per_chunk, u64* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* rows_s = smem_raw;
     u64* thr = reinterpret_cast<u64*>(smem_raw + ST_ROWS * ST_LDB);
@@ -699,55 +694,6 @@ __global__ __launch_bounds__(ST_ROWS, 2) void stream_search_kernel(
 
     __syncthreads();
     for (int i = tid; i < NQ * k; i += ST_ROWS) partial[(size_t)chunk * NQ * k + i] = list[i];
-    if (arrivals == nullptr) return;
-    // ---- the LAST workgroup to get here merges the partial lists (a separate merge launch is one more graph node, ~5 us
-    // of a single request's ~0.3 ms, around a tournament whose every round waited for a global load): every workgroup
-    // publishes its lists (release fence) and draws a ticket; the holder of the last ticket reads all
-    // gridDim.x * k keys of a query (<= STREAM_FUSED_MERGE_KEYS, checked by the host) into registers, 16 per thread, and
-    // extracts the k largest by k rounds of a block-wide maximum.  Keys are unique (score bits | row), so every round
-    // removes exactly one.  Same (score desc, row asc) order as merge_kernel, same outputs.
-    __threadfence();
-    __syncthreads();
-    int* tick_s = cnt;  // LDS scratch (the queue counters are dead)
-    if (tid == 0) tick_s[0] = atomicAdd(arrivals, 1);
-    __syncthreads();
-    if (tick_s[0] != (int)gridDim.x - 1) return;
-    __threadfence();
-    const int n_keys = (int)gridDim.x * k;
-    u64* wmax = thr;  // 8 x u64 of LDS scratch
-    for (int j = 0; j < Q; ++j) {
-        u64 mine[STREAM_FUSED_MERGE_KEYS / ST_ROWS];
-#pragma unroll
-        for (int s = 0; s < STREAM_FUSED_MERGE_KEYS / ST_ROWS; ++s) {
-            const int f = tid + ST_ROWS * s;
-            const int c = f / k, e = f - c * k;
-            mine[s] = f < n_keys ? __hip_atomic_load(partial + ((size_t)c * NQ + j) * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        }
-        for (int e = 0; e < k; ++e) {
-            u64 best = 0ull;
-#pragma unroll
-            for (int s = 0; s < STREAM_FUSED_MERGE_KEYS / ST_ROWS; ++s) best = mine[s] > best ? mine[s] : best;
-            const u64 wv = wave_max_u64(best);
-            __syncthreads();  // the previous round's maxima have been read
-            if (lane == 0) wmax[wave] = wv;
-            __syncthreads();
-            u64 w = wmax[0];
-#pragma unroll
-            for (int v = 1; v < ST_ROWS / 64; ++v) w = wmax[v] > w ? wmax[v] : w;
-            if (w != 0ull) {
-#pragma unroll
-                for (int s = 0; s < STREAM_FUSED_MERGE_KEYS / ST_ROWS; ++s)
-                    if (mine[s] == w) mine[s] = 0ull;
-            }
-            if (tid == 0) {
-                if (out_keys) out_keys[(size_t)j * k + e] = w;
-                if (out_idx) {
-                    out_idx[(size_t)j * k + e] = w ? (int64_t)key_row(w) : -1;
-                    out_score[(size_t)j * k + e] = w ? key_score(w) : 0.0f;
-                }
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------- filter + verify (ICREC_ROWS_F32_FILTER)
@@ -1039,18 +985,17 @@ static Plan make_plan(const Index* ix, int Q, int k, bool allow_stream) {
     }
     p.ws_q = ((size_t)p.Qpad * ix->dim * 4 + 255) & ~(size_t)255;
     p.ws_partial = ((size_t)p.n_chunks * p.Qpad * k * 8 + 255) & ~(size_t)255;
-    p.ws_total = p.ws_q + p.ws_partial + 256;  // + the arrival counter of the streaming variant's fused merge
+    p.ws_total = p.ws_q + p.ws_partial;
     return p;
 }
 
 template <int NQ, bool P16>
 static int launch_stream(const Index* ix, const Plan& p, const float* qn, int Q, int k, const int32_t* ei,
-                         const int32_t* eo, u64* partial, hipStream_t st, int* arrivals, int64_t* out_idx,
-                         float* out_score, u64* out_keys) {
+                         const int32_t* eo, u64* partial, hipStream_t st) {
     ScopedTimer tm(T_SEARCH_KERNEL, st);
     hipLaunchKernelGGL((stream_search_kernel<NQ, P16>), dim3(p.n_chunks), dim3(ST_ROWS), p.smem, st, (const void*)ix->rows,
                        ix->n_rows, ix->dim, qn, Q, k, ei, eo, (uint32_t)ix->row_offset, p.n_row_tiles, p.tiles_per_chunk,
-                       partial, arrivals, out_idx, out_score, out_keys);
+                       partial);
     ICREC_HIP(hipGetLastError());
     return ICREC_OK;
 }
@@ -1210,12 +1155,8 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     ScopedTimer whole(T_SEARCH, st);
     float* qn = reinterpret_cast<float*>(ws);
     u64* partial = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + p.ws_q);
-    // streaming variant with few enough partial keys: its last workgroup merges them itself (no merge launch); the
-    // arrival counter sits behind the partial lists in the workspace and is zeroed by the normalisation kernel
-    const bool fused_merge = p.variant == 3 && (out_idx || out_keys) && (int64_t)p.n_chunks * k <= STREAM_FUSED_MERGE_KEYS;
-    int* arrivals = fused_merge ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + p.ws_q + p.ws_partial) : nullptr;
     hipLaunchKernelGGL(normalize_rows_kernel<false>, dim3((p.Qpad + 3) / 4), dim3(256), 0, st, q, (void*)qn, (int64_t)Q,
-                       (int64_t)p.Qpad, ix->dim, 1e-12f, p.variant == 3 ? p.Qpad : 0, arrivals);
+                       (int64_t)p.Qpad, ix->dim, 1e-12f, p.variant == 3 ? p.Qpad : 0);
     int rc;
 #define ICREC_SEARCH_DISPATCH(EMIT, P16)                                                                            \
     (p.variant == 0   ? launch_search<CfgBig, EMIT, P16>(ix, p, qn, Q, k, ei, eo, partial, scores_out, st)          \
@@ -1224,8 +1165,7 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     if (p.variant == 3) {
         const bool h = rows_are_bf16(ix);
 #define ICREC_STREAM_DISPATCH(NQ) \
-    (h ? launch_stream<NQ, true>(ix, p, qn, Q, k, ei, eo, partial, st, arrivals, out_idx, out_score, out_keys)                     \
-       : launch_stream<NQ, false>(ix, p, qn, Q, k, ei, eo, partial, st, arrivals, out_idx, out_score, out_keys))
+    (h ? launch_stream<NQ, true>(ix, p, qn, Q, k, ei, eo, partial, st) : launch_stream<NQ, false>(ix, p, qn, Q, k, ei, eo, partial, st))
         rc = p.BN == 1 ? ICREC_STREAM_DISPATCH(1) : p.BN == 2 ? ICREC_STREAM_DISPATCH(2) : p.BN == 4 ? ICREC_STREAM_DISPATCH(4)
                                                                                                    : ICREC_STREAM_DISPATCH(8);
 #undef ICREC_STREAM_DISPATCH
@@ -1233,7 +1173,7 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
     else rc = scores_out ? ICREC_SEARCH_DISPATCH(true, false) : ICREC_SEARCH_DISPATCH(false, false);
 #undef ICREC_SEARCH_DISPATCH
     if (rc != ICREC_OK) return rc;
-    if ((out_idx || out_keys) && !fused_merge) {
+    if (out_idx || out_keys) {
         if (p.n_chunks <= 256)
             hipLaunchKernelGGL(merge_kernel<4>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k,
                                out_idx, out_score, out_keys);

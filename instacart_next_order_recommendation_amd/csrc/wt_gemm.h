@@ -212,16 +212,16 @@ __device__ unsigned long long g_stamps[1 << 22];
 
 // ---------------------------------------------------------------- whole-K loop of one output tile
 // acc[i][tt] = sum_k W[(nt0 + i) block][k] . X[m0 + tt block][k], K in slabs of 64 (2 k-steps of 32); weight fragments
-// D k-steps ahead in registers (D = 1, 2, 4 or 8: the latency form of single requests keeps four, eight over the 48 k-steps
-// of FFN-down - its few workgroups find a layer's fragments in the Infinity Cache at best, half a microsecond away), the next activation slab one slab
+// D k-steps ahead in registers (D = 1, 2 or 4: the latency form of single requests keeps four - its few workgroups
+// find a layer's fragments in the Infinity Cache at best, half a microsecond away; eight over the 48 k-steps of FFN-down
+// measured 5 us SLOWER per request, round 4), the next activation slab one slab
 // ahead in registers, two LDS stages, one barrier per slab.  `smem`: XRing<TTW>::BYTES.  The fragments of the next (k-step, token block) unit are read from LDS
 // under the current unit's MFMAs.
 template <int NTW, int TTW, int D>
 __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16* __restrict__ Wp, int nt0, int K,
                                          const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, int64_t m0,
                                          int64_t T, char* smem) {
-    static_assert(D == 1 || D == 2 || D == 4 || D == 8, "prefetch depth: 1, 2, 4 or 8 k-steps");
-    constexpr int NPAR = D == 8 ? 4 : 2;  // slabs per trip of the unrolled loop: the ring slot of k-step 2 s + j is (2 (s % NPAR) + j) % D
+    static_assert(D == 1 || D == 2 || D == 4, "prefetch depth: 1, 2 or 4 k-steps");
     static_assert(TTW == 1 || TTW == 2, "1 or 2 token blocks per wave");
     ICREC_STAMP(0, 0);
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16*
     __syncthreads();
     ICREC_STAMP(0, 1);
     auto slab = [&](int s, auto parity, u32x4 (&xnext)[2 * TTW]) {  // xnext holds slab s+1 on entry, slab s+3 on exit
-        constexpr int PAR = decltype(parity)::value;  // s % NPAR
+        constexpr int PAR = decltype(parity)::value;  // s & 1: the ring slot of k-step 2 s + j is (2 PAR + j) % D
         const char* st = smem + (s & 1) * XRing<TTW>::STAGE_BYTES;
         XFrag x[2];  // unit u = j * TTW + tt: the next unit's fragments are read under the current one's MFMAs
         x_frag<TTW>(x[0], st, 0, 0, c, g);
@@ -277,13 +277,9 @@ __device__ __forceinline__ void wt_kloop(Acc32 (&acc)[NTW][TTW], const _Float16*
         __syncthreads();
         if (s < 24) ICREC_STAMP(0, 2 + s);
     };
-    for (int s = 0; s < nslab; s += NPAR) {  // nslab is a multiple of NPAR (K a multiple of 128; of 256 where D == 8 is used)
+    for (int s = 0; s < nslab; s += 2) {  // nslab is even (K is a multiple of 128 for every layer of the encoder)
         slab(s, std::integral_constant<int, 0>{}, xb);
         slab(s + 1, std::integral_constant<int, 1>{}, xa);
-        if constexpr (NPAR == 4) {
-            slab(s + 2, std::integral_constant<int, 2>{}, xb);
-            slab(s + 3, std::integral_constant<int, 3>{}, xa);
-        }
     }
 }
 

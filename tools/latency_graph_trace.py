@@ -30,7 +30,24 @@ def run(n_tok: int) -> None:
         a = time.perf_counter()
         fast.run(one, 20)
         lat.append((time.perf_counter() - a) * 1e3)
-    print(f"p50 host-to-host {np.median(lat[20:]):.4f} ms over {len(lat) - 20} replays ({n_tok} tokens)")
+    # the same replay between two events (GPU-side span of the graph alone) and the host cost of the pieces of run()
+    cap = next(iter(fast._graphs.values()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    span, t_replay, t_sync = [], [], []
+    st = torch.cuda.current_stream()
+    for _ in range(60):
+        cap.d_in.copy_(cap.h_in, non_blocking=True)
+        e0.record(st)
+        a = time.perf_counter()
+        cap.graph.replay()
+        b = time.perf_counter()
+        e1.record(st)
+        st.synchronize()
+        c = time.perf_counter()
+        span.append(e0.elapsed_time(e1)); t_replay.append((b - a) * 1e3); t_sync.append((c - b) * 1e3)
+    print(f"p50 host-to-host {np.median(lat[20:]):.4f} ms over {len(lat) - 20} replays ({n_tok} tokens); graph between events "
+          f"{np.median(span[10:]):.4f} ms; host time inside graph.replay() {np.median(t_replay[10:]):.4f} ms, then waiting "
+          f"{np.median(t_sync[10:]):.4f} ms")
 
 
 def summary(out: str) -> None:
