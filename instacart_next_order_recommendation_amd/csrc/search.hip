@@ -892,6 +892,70 @@ __global__ __launch_bounds__(256) void merge_kernel(const u64* __restrict__ keys
     }
 }
 
+// Few queries, few lists (a single request: ~200 partial lists of k): ONE global round trip and three short LDS passes
+// instead of k dependent rounds (merge_kernel's every round waits for a global load behind a 12-shuffle wave maximum:
+// 12 us of a 0.35 ms request at 195 lists x 20).  A 256-thread workgroup per query:
+//   1. all n_lists * k keys (<= MERGE_BLOCK_KEYS) -> LDS, coalesced;
+//   2. h = the k-th largest list HEAD (rank by counting over the <= 256 heads): at least k keys are >= h, so the k
+//      best keys are all >= h, and only lists whose head is >= h (at most k of them) hold any;
+//   3. those lists hand their keys >= h to a candidate array (they are sorted: stop at the first smaller one);
+//   4. every candidate's rank by counting; rank r < k goes to output r.  Keys are unique (score bits | row) and 0 is
+//      the empty pad, so ranks are exact: the same (score desc, row asc) order and outputs as merge_kernel.
+constexpr int MERGE_BLOCK_KEYS = 16 * 256;
+__global__ __launch_bounds__(256) void merge_block_kernel(const u64* __restrict__ keys, int n_lists, int q_stride, int Q,
+                                                          int k, int64_t* __restrict__ out_idx,
+                                                          float* __restrict__ out_score, u64* __restrict__ out_keys) {
+    __shared__ __attribute__((aligned(16))) u64 all[MERGE_BLOCK_KEYS];
+    __shared__ uint16_t cand[MERGE_BLOCK_KEYS];  // candidates as indices into `all`
+    __shared__ u64 h_s;
+    __shared__ int ncand;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const int n_keys = n_lists * k;
+    if (tid == 0) { h_s = 0ull; ncand = 0; }
+#pragma unroll
+    for (int s = 0; s < MERGE_BLOCK_KEYS / 256; ++s) {
+        const int f = tid + 256 * s;
+        if (f < n_keys) {
+            const int c = f / k, e = f - c * k;
+            all[f] = keys[((size_t)c * q_stride + q) * k + e];
+        }
+    }
+    __syncthreads();
+    const u64 head = tid < n_lists ? all[tid * k] : 0ull;
+    if (head != 0ull) {
+        int r = 0;
+        for (int i = 0; i < n_lists; ++i) r += all[i * k] > head ? 1 : 0;  // LDS broadcast reads
+        if (r == k - 1) h_s = head;  // unique keys: at most one thread
+    }
+    __syncthreads();
+    const u64 h = h_s;  // 0 when fewer than k lists are non-empty: every key is a candidate
+    if (head != 0ull && head >= h) {
+        for (int e = 0; e < k; ++e) {
+            const u64 v = all[tid * k + e];
+            if (v == 0ull || v < h) break;
+            cand[atomicAdd(&ncand, 1)] = (uint16_t)(tid * k + e);
+        }
+    }
+    __syncthreads();
+    const int C = ncand;
+    for (int ci = tid; ci < C; ci += 256) {
+        const u64 v = all[cand[ci]];
+        int r = 0;
+        for (int j = 0; j < C; ++j) r += all[cand[j]] > v ? 1 : 0;
+        if (r < k) {
+            const size_t o = (size_t)q * k + r;
+            if (out_keys) out_keys[o] = v;
+            if (out_idx) { out_idx[o] = (int64_t)key_row(v); out_score[o] = key_score(v); }
+        }
+    }
+    for (int e = (C < k ? C : k) + tid; e < k; e += 256) {  // pads: fewer than k rows left after the exclusions
+        const size_t o = (size_t)q * k + e;
+        if (out_keys) out_keys[o] = 0ull;
+        if (out_idx) { out_idx[o] = -1; out_score[o] = 0.0f; }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 struct Index {
     void* rows = nullptr;  // normalised [n_rows, dim], fp32 or bf16 bits
@@ -1174,7 +1238,10 @@ static int run_search(Index* ix, const float* q, int Q, int k, const int32_t* ei
 #undef ICREC_SEARCH_DISPATCH
     if (rc != ICREC_OK) return rc;
     if (out_idx || out_keys) {
-        if (p.n_chunks <= 256)
+        if (Q <= 4 && p.n_chunks <= 256 && (int64_t)p.n_chunks * k <= MERGE_BLOCK_KEYS)
+            hipLaunchKernelGGL(merge_block_kernel, dim3(Q), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k, out_idx,
+                               out_score, out_keys);
+        else if (p.n_chunks <= 256)
             hipLaunchKernelGGL(merge_kernel<4>, dim3((Q + 3) / 4), dim3(256), 0, st, partial, p.n_chunks, p.Qpad, Q, k,
                                out_idx, out_score, out_keys);
         else
