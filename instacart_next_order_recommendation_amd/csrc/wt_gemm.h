@@ -53,19 +53,25 @@ __device__ __forceinline__ void split_scaled(float x, float scale, _Float16& hi,
     hi = (_Float16)s;
     lo = (_Float16)(s - (float)hi);
 }
-// Activations are split on the fly (LayerNorm / GELU / attention epilogues), so their split is the cheap form:
-//   s = 16 x;  hi = s with the low 13 mantissa bits cleared (exactly an 11-bit value, i.e. an f16 for normal
-//   magnitudes);  lo = s - hi (exact in fp32);  both converted with v_cvt_pkrtz_f16_f32, two elements per instruction
-// = 3 VALU per element instead of 6.  hi + lo still carries s to 2^-21 relative (lo is rounded toward zero: one ulp of
-// an 11-bit residual); below the f16 normal range (|x| < 3.8e-6) the absolute error is < 2^-24 / 16; beyond it
-// (|x| > 4094) the conversion saturates at +-65504 instead of overflowing.  Every producer of activation planes uses
-// this one function, so a tensor's planes are the same bits whichever kernel wrote them.
+// Activations are split on the fly (LayerNorm / GELU / attention epilogues), so their split is the cheap form, four
+// instructions per PAIR of elements:
+//   s = 16 x;  hi = f16(s) rounded toward zero (v_cvt_pkrtz_f16_f32: two elements per instruction);
+//   lo = f16(s - hi), the subtraction by v_fma_mix_f32 (hi read as the f16 it is, times -1, plus s: exact in fp32, no
+//   conversion back), again v_cvt_pkrtz.
+// (Rounds 1-3 built hi by clearing the low 13 mantissa bits of s: the same value wherever s is in f16's normal range,
+// six instructions per pair.  The attention kernels are bound by vector issue - 4.5 waves per SIMD at ~20 % VALU each -
+// and a third of their per-score work was this split.)  hi + lo carries s to 2^-21 relative (lo is rounded toward zero:
+// one ulp of an 11-bit residual); below the f16 normal range (|x| < 3.8e-6) the absolute error is < 2^-24 / 16; beyond
+// it (|x| > 4094) hi saturates at +-65504 and lo takes what it can of the rest.  Every producer of activation planes
+// uses this one function, so a tensor's planes are the same bits whichever kernel wrote them.
 typedef _Float16 half2w __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair_prescaled(float s0, float s1, half2w& hi, half2w& lo) {
-    const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
-    const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
-    hi = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    lo = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(s0 - h0, s1 - h1));
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s0, s1));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(s0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(s1));
+    hi = __builtin_bit_cast(half2w, h);
+    lo = __builtin_bit_cast(half2w, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 // four consecutive elements, already multiplied by the plane scale -> the 8-byte hi and lo pieces
 __device__ __forceinline__ void split4_prescaled(const f32x4& s, half4& hi, half4& lo) {

@@ -6,7 +6,7 @@ set -e
 P=instacart_next_order_recommendation_amd
 R=${1:-2}; O=${2:-gpurun_out/ab}; shift 2 || true
 cp $P/libicrec.so /tmp/icrec_B.so
-cp $P/libicrec_prev.so /tmp/icrec_A.so
+cp ${ICREC_AB_A:-$P/libicrec_prev.so} /tmp/icrec_A.so
 for i in $(seq 1 $R); do
   for v in A B; do
     cp /tmp/icrec_$v.so $P/libicrec.so
