@@ -214,7 +214,7 @@ __device__ __forceinline__ void r32_mma(f32x16 (&acc)[1][2], const half8& wh, co
 #define ICREC_STAMP_ROUND0 0  // tools/search_stamps.hip: first round of a block whose phases are stamped
 #endif
 template <class Cfg, bool EMIT, int PMODE>
-__global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) void search_kernel(
+__global__ __launch_bounds__(Cfg::THREADS, 2) void search_kernel(
     const void* __restrict__ P, const void* __restrict__ P2, int64_t N, int K, const void* __restrict__ Qn,
     const void* __restrict__ Q2, int Qpad, int Q, int k, const int32_t* __restrict__ excl_idx,
     const int32_t* __restrict__ excl_off, uint32_t row_base, int n_row_tiles, int tiles_per_chunk, int n_qtiles,
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(Cfg::THREADS, (PMODE == 3 && Cfg::TM > 1 ? 1 : 2)) 
     int xb0[2] = {0, 0};
     const unsigned lo8 = lane * 8;
     if constexpr (PMODE == 3) {
-        static_assert(PMODE != 3 || (Cfg::TM <= 2 && Cfg::TN == 2 && Cfg::WAVES_N == 1 && Cfg::WAVES_M == 8),
-                      "resident pass: 8 waves x (1-2 row tiles x 2 query tiles)");
+        static_assert(PMODE != 3 || (Cfg::TM == 1 && Cfg::TN == 2 && Cfg::WAVES_N == 1 && Cfg::WAVES_M == 8),
+                      "resident pass: 8 waves x (1 row tile x 2 query tiles)");
         const _Float16* qh = static_cast<const _Float16*>(Qn);
         const _Float16* ql = static_cast<const _Float16*>(Q2);
         char* const Xs = smem_raw;

@@ -316,6 +316,44 @@ def test_filter_index_is_bit_identical_to_exact(torch_cuda, monkeypatch, residen
     np.testing.assert_array_equal(sc2.cpu().numpy(), want_s)
 
 
+@pytest.mark.parametrize("order", ["ascending", "random"])
+def test_resident_filter_long_blocks_ascending_scores(torch_cuda, order):
+    """4,096 queries over 49,688 rows give every block of the resident filter pass 49 rounds.  "ascending": rows ordered
+    so that every query's score GROWS with the row number - every round brings 256 rows better than anything the block
+    has seen, so every round floods the candidate queues (offers that do not fit wait for the next merge iteration): the
+    worst case of the selection.  Result: bit-identical to the exact index on all queries, to the oracle on a sample;
+    with exclusion lists that knock out some of the very best rows.  (Written in round 4 for a barrier-free form of the
+    selection that was measured and dropped, profiles/r04_search_epoch_mode_ab.txt; kept as the adversarial case.)"""
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    n, nq, k = 49_688, 4096, 20
+    d = rng.standard_normal(384).astype(np.float32)
+    d /= np.linalg.norm(d)
+    u = rng.standard_normal(384).astype(np.float32)
+    u -= u.dot(d) * d
+    u /= np.linalg.norm(u)
+    t = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    if order == "random":
+        t = rng.permutation(t)
+    P = u[None, :] + t[:, None] * d[None, :] + 0.02 * rng.standard_normal((n, 384)).astype(np.float32)
+    q = d[None, :] + 0.02 * rng.standard_normal((nq, 384)).astype(np.float32)
+    excl = [rng.choice(n, size=int(rng.integers(0, 30)), replace=False).tolist() if i % 3 == 0 else [] for i in range(nq)]
+    if order == "ascending":  # also knock out a few of the very best rows of some queries
+        for i in range(0, nq, 7):
+            excl[i] = sorted(set(excl[i]) | {n - 1, n - 2, n - 5})
+    Pd, qd = torch.from_numpy(P).cuda(), torch.from_numpy(q).cuda()
+    fi = _search_mod().DeviceIndex(Pd, storage="f32+filter")
+    ei = _search_mod().DeviceIndex(Pd, storage="f32")
+    idx, sc = fi.search(qd, k, excl)
+    xi, xs = ei.search(qd, k, excl)
+    assert torch.equal(idx, xi) and torch.equal(sc, xs)
+    sample = [0, 1, 7, 63, 64, 2047, 4095]
+    wi, ws = _oracle().search(q[sample], P, k, [excl[i] for i in sample])
+    np.testing.assert_array_equal(idx[sample].cpu().numpy(), wi)
+    np.testing.assert_array_equal(sc[sample].cpu().numpy(), ws)
+    fi.close(); ei.close()
+
+
 def test_filter_falls_back_when_it_cannot_prove_the_result(torch_cuda):
     """Adversarial ties: 300 identical rows (more than any candidate list holds) are every query's best match,
     plus blocks of near-ties 1e-6 apart.  The verify pass cannot prove these, raises its flag, and the exact
