@@ -19,8 +19,13 @@ def _frontend(sock_path: str, host: str, port: int, ready) -> None:
     os.environ["ICREC_GPU_WORKER_SOCKET"] = sock_path
     from .app import app
     from .fastserve import serve
+    from .worker import _settle_heap
 
-    asyncio.run(serve(app, host, port, reuse_port=True, ready=ready.set))
+    def on_ready():
+        _settle_heap()  # the corpus texts are loaded by now (lifespan): keep them out of later full collections
+        ready.set()
+
+    asyncio.run(serve(app, host, port, reuse_port=True, ready=on_ready))
 
 
 def _worker(sock_path: str, model_dir: str, corpus_path: str, ready) -> None:
