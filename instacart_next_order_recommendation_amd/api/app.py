@@ -83,6 +83,10 @@ async def lifespan(app: FastAPI) -> AsyncIterator[None]:
         _install(app, MonitoredRecommender(model_dir=model_dir, corpus_path=corpus_path), corpus_path)
     app.state.ready = True
     MODEL_LOADED.set(1)
+    import gc
+
+    gc.collect()
+    gc.freeze()  # the catalog and the modules live as long as the process: keep full collections away from them (worker.py)
     try:
         yield
     finally:
