@@ -162,11 +162,11 @@ def roofline(mode: str, achieved: float, n: int, ms: float, flops: float, tokens
             # every 64-token workgroup pulls the layer's Wo/W1/W2 fragments + its planes through its vector L1
             "l2_stream": {"bytes_per_launch": l2_bytes,
                           "TBps_at_this_launch_time": l2_bytes / (ms * 1e-3) / 1e12 if ms > 0 else None,
-                          "note": "L2 -> L1 bytes per launch BY CONSTRUCTION (one pass over the layer's fragments + the block's "
-                                  "planes per 64-token workgroup), an upper figure: the PMC count of the committed profile is "
-                                  "lower (TCP_TCC_READ_REQ x 128 B, profiles/README.md has the reconciliation) because "
-                                  "requests that hit in the vector L1 never reach L2; not a wall either way: the same access "
-                                  "pattern without arithmetic streams 23-32 TB/s (tools/l2_stream.hip, "
+                          "note": "L2 -> L1 bytes per launch BY CONSTRUCTION (one pass over the layer's fragments + the block's planes "
+                                  "per 64-token workgroup), averaged over a step's launches (5 of 6 stream the next layer's Wqkv too). "
+                                  "Counter check (TCP_TCC_READ_REQ x 128 B, profiles/r04_pmc_l2_stream.txt): 11.65 GB for the last "
+                                  "layer's launch against 11.3 GB by construction for that launch; profiles/README.md has the table. "
+                                  "Not a wall: the same access pattern without arithmetic streams 23-32 TB/s (tools/l2_stream.hip, "
                                   "profiles/r03_l2_stream_microbench.txt)"},
             "launches_timed": n, "avg_launch_ms": ms, "flops_per_launch": flops, "tokens_per_launch": tokens}
 
