@@ -103,3 +103,37 @@ def test_synthetic_formats():
     assert (ids[cu[:-1]] == 101).all() and (ids[cu[1:] - 1] == 102).all()
     e = syn.synthetic_embeddings(100, 384, seed=5)
     assert np.abs(np.linalg.norm(e.astype(np.float64), axis=1) - 1).max() < 1e-6
+
+
+def test_bench_bare_multi_gpu_form_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 4` without WORLD_SIZE (the form the driver uses) must not die at start-up: it
+    re-launches itself under torch.distributed.run as a CHILD process - before importing torch or touching a GPU - with the same
+    arguments, a loopback rendezvous, and exits with the child's code."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("bench_under_test", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    imported_before = "torch" in sys.modules
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7                                   # the child's exit code
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert ("torch" in sys.modules) == imported_before           # decided before torch is imported by bench.main
