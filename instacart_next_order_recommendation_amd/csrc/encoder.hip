@@ -810,6 +810,14 @@ template <int EPI>
 static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int K, const _Float16* Wp, int N,
                              const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
     if (T <= X3_SMALL_M) {
+        if constexpr (EPI == 0 || EPI == 2) {  // 16-feature tiles per wave, twice the workgroups (wt_linear_half_kernel)
+            if (N % 64 == 0 && K % 128 == 0) {
+                const int nbn = N / 64;
+                hipLaunchKernelGGL((wt_linear_half_kernel<EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K, Wp, N,
+                                   bias, out, (const _Float16*)oh, (const _Float16*)ol, nbn);
+                return;
+            }
+        }
         const int nbn = N / 128;
         hipLaunchKernelGGL((wt_linear_kernel<1, 1, 4, EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K,
                            Wp, N, bias, out, oh, ol, nbn);
@@ -1016,7 +1024,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     batch_split(e, T, &T_main, &T_tail);
     const bool fuse = e->fuse, side_stream = e->side_stream;
     const bool qkv_res = fuse && H == 384;
-    const bool lnin = fuse && H == 384 && I % 128 == 0;  // small ranges: LayerNorms folded into the consuming GEMMs
+    const bool lnin = fuse && H == 384 && I % 64 == 0;  // small ranges: LayerNorms folded into the consuming GEMMs
     const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
     Encoder::Side* sd = nullptr;
     if (x3 && side_stream && (T_tail || split_att))
@@ -1063,8 +1071,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     // small ranges: the previous layer's FFN LayerNorm is this kernel's prologue (t1 rows -> planes in LDS
                     // and, from the workgroups of feature block 0, to xh / xl): one graph node fewer per layer
                     const LayerW& Lp = e->layers[l - 1];
-                    const int nbn = 3 * H / 128;
-                    hipLaunchKernelGGL((wt_linear_lnin_kernel<0>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
+                    const int nbn = 3 * H / 64;
+                    hipLaunchKernelGGL((wt_linear_lnin_kernel<0, true>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
                                        (const float*)(t1 + (size_t)r0 * H), Tn, Lp.g2, Lp.b2n, c.ln_eps, xh + (size_t)r0 * H,
                                        xl + (size_t)r0 * H, L.Wqkv_p, 3 * H, L.bqkv, qkv + (size_t)r0 * 3 * H,
                                        (_Float16*)nullptr, (_Float16*)nullptr, nbn);
@@ -1096,8 +1104,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
                     launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes
                     if (lnin && Tn <= X3_SMALL_M) {  // LayerNorm + FFN-up in one node (wt_linear_lnin_kernel)
-                        const int nbn = I / 128;
-                        hipLaunchKernelGGL((wt_linear_lnin_kernel<1>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
+                        const int nbn = I / 64;
+                        hipLaunchKernelGGL((wt_linear_lnin_kernel<1, true>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
                                            (const float*)t1r, Tn, L.g1, L.b1n, c.ln_eps, xhr, xlr, L.W1_p, I, L.b1,
                                            (float*)nullptr, hhr, hlr, nbn);
                     } else {

@@ -532,6 +532,98 @@ __device__ __forceinline__ void ffn_x_frag(XFrag& x, const char* Xs, const int (
     }
 }
 
+// ---------------------------------------------------------------- small batches: every GEMM on twice as many CUs
+// A single request's GEMMs are a handful of workgroups, each pulling its weight fragments through ONE CU's vector L1: FFN-down
+// (K = 1,536: 48 k-steps, the longest dependent chain of a request) moved 768 KB per 32-token x 128-feature workgroup, twelve
+// workgroups in all.  Here a wave owns ONE 16-feature tile (half a 32-feature block: two of a k-step's four fragments, six
+// MFMAs) and a workgroup 32 tokens x 64 features: twice the workgroups, half the bytes and half the MFMA chain per CU
+// (measured, same box: FFN-down -12 us per request, attention-out another -10 us; profiles/r04_single_request_anatomy.txt).
+// Per output the chain is wt_kloop's (k-steps ascending, (w_hi,x_hi), (w_lo,x_hi), (w_hi,x_lo)): identical bits.
+template <int EPI>  // 0: out = acc * 2^-14 + bias; 2: residual planes rh / rl + bias added after the loop, out = that * 2^-14
+__global__ __launch_bounds__(256, 2) void wt_linear_half_kernel(const _Float16* __restrict__ Xh,
+                                                                    const _Float16* __restrict__ Xl, int T, int K,
+                                                                    const _Float16* __restrict__ Wp, int N,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    const _Float16* __restrict__ rh,
+                                                                    const _Float16* __restrict__ rl, int n_blocks_n) {
+    __shared__ __attribute__((aligned(16))) char smem[XRing<1>::BYTES];
+    const int lane = threadIdx.x & 63, q = wave_uniform(threadIdx.x >> 6), c = lane & 15, g = lane >> 4;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
+    const int64_t m0 = (int64_t)mt * 32;
+    const int ft = nb * 4 + q, nt = ft >> 1, fi = ft & 1;  // 16-feature tile, its 32-feature block, which half
+    const unsigned lo8 = lane * 8;
+    const int KS = K / 32, nslab = K / 64;
+    const _Float16* const wp = Wp + wt_frag_off(nt, 0, KS) + (size_t)fi * (2 * WT_FRAG);
+    half8 wh[4], wl[4];
+    auto w_load1 = [&](int slot, int ks) {
+        const _Float16* p = wp + (size_t)ks * (4 * WT_FRAG);
+        wh[slot] = *reinterpret_cast<const half8*>(p + lo8);
+        wl[slot] = *reinterpret_cast<const half8*>(p + WT_FRAG + lo8);
+    };
+    f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+    u32x4 xa[2], xb[2];
+    x_load<1>(xa, Xh, Xl, m0, T, K, 0);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w_load1(d, d);
+    if (nslab > 1) x_load<1>(xb, Xh, Xl, m0, T, K, 1);
+    x_store<1>(xa, smem);
+    if (nslab > 2) x_load<1>(xa, Xh, Xl, m0, T, K, 2);
+    __syncthreads();
+    auto slab = [&](int s, auto parity, u32x4 (&xnext)[2]) {  // as wt_kloop<1, 1, 4>: ring slot of k-step 2 s + j is 2 PAR + j
+        constexpr int PAR = decltype(parity)::value;
+        const char* st = smem + (s & 1) * XRing<1>::STAGE_BYTES;
+        XFrag x[2];
+        x_frag<1>(x[0], st, 0, 0, c, g);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 0) {
+                x_frag<1>(x[1], st, 0, 1, c, g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[2 * PAR + j], x[j].h[ti], acc[ti], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[2 * PAR + j], x[j].h[ti], acc[ti], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[2 * PAR + j], x[j].l[ti], acc[ti], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int nk = 2 * s + j + 4;
+            nk = nk < KS ? nk : KS - 1;
+            w_load1(2 * PAR + j, nk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s + 1 < nslab) {
+            x_store<1>(xnext, smem + ((s + 1) & 1) * XRing<1>::STAGE_BYTES);
+            if (s + 3 < nslab) x_load<1>(xnext, Xh, Xl, m0, T, K, s + 3);
+        }
+        __syncthreads();
+    };
+    for (int s = 0; s < nslab; s += 2) {
+        slab(s, std::integral_constant<int, 0>{}, xb);
+        slab(s + 1, std::integral_constant<int, 1>{}, xa);
+    }
+    const int feat = nt * 32 + fi * 16 + 4 * g;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int64_t tok = m0 + ti * 16 + c;
+        if (tok < T) {
+            f32x4 v;
+            if constexpr (EPI == 2) {
+                const half4 a = *reinterpret_cast<const half4*>(rh + tok * N + feat);
+                const half4 d = *reinterpret_cast<const half4*>(rl + tok * N + feat);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (acc[ti][j] + res_init_val(a[j], d[j], b[j])) * WT_UNSCALE;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[ti][j], WT_UNSCALE, b[j]);
+            }
+            *reinterpret_cast<f32x4*>(out + tok * N + feat) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- small batches: LayerNorm folded into the consuming GEMM
 // A replayed hipGraph pays ~5 us per node whatever the node does (profiles/r04_single_request_anatomy.txt), and a single
 // request's LayerNorm nodes did 5 us of nothing else.  The two K = 384 GEMMs that CONSUME a LayerNorm's output (FFN-up
@@ -544,7 +636,7 @@ __device__ __forceinline__ void ffn_x_frag(XFrag& x, const char* Xs, const int (
 // straight-line k-steps off the image, one 32 x 32 block per wave, per output the chain of wt_kloop (same bits as
 // wt_linear_kernel<1, 1, 4, EPI> on ln_wt_kernel's planes).  EPI 0: fp32 out + bias; EPI 1: erf-GELU planes.
 constexpr int LNIN_XPLANE = 32 * 768;
-template <int EPI>
+template <int EPI, bool HALF = false>  // HALF: a wave owns one 16-feature tile (64 features per workgroup) instead of a 32-feature block
 __global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __restrict__ a, int T,
                                                                 const float* __restrict__ gam,
                                                                 const float* __restrict__ bet, float eps,
@@ -559,15 +651,25 @@ __global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __r
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = bid / n_blocks_n, nb = bid % n_blocks_n;
     const int64_t m0 = (int64_t)mt * 32;
-    const int nt = nb * 4 + wq;
+    const int ft = nb * 4 + wq;                       // HALF: 16-feature tile index
+    const int nt = HALF ? ft >> 1 : ft, hf = ft & 1;  // the 32-feature block; HALF: which half of it
     const unsigned lo8 = lane * 8;
-    WFrag w[4][1];
+    WFrag w[4][1];  // HALF: only [hf] of h / l is loaded and used
     const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
+    auto w_ring_load = [&](int slot, int ks) {
+        if constexpr (HALF) {
+            const _Float16* p = wp1[0] + (size_t)ks * (4 * WT_FRAG) + (size_t)hf * (2 * WT_FRAG);
+            w[slot][0].h[0] = *reinterpret_cast<const half8*>(p + lo8);
+            w[slot][0].l[0] = *reinterpret_cast<const half8*>(p + WT_FRAG + lo8);
+        } else {
+            w_load<1>(w[slot], wp1, ks, lo8);
+        }
+    };
 #pragma unroll
-    for (int d = 0; d < 4; ++d) w_load<1>(w[d], wp1, d, lo8);
+    for (int d = 0; d < 4; ++d) w_ring_load(d, d);
     f32x4 bv[2];
 #pragma unroll
-    for (int fi = 0; fi < 2; ++fi) bv[fi] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + fi * 16 + 4 * g);
+    for (int fi = 0; fi < 2; ++fi) bv[fi] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + (HALF ? hf : fi) * 16 + 4 * g);
     // ---- LayerNorm of the block's 32 rows: two passes of 16 tokens, ln_wt_kernel's thread mapping and order
     {
         const int slot = tid & 15, q = slot >> 2, gg = slot & 3;
@@ -654,13 +756,22 @@ __global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __r
             x_frag1(x[(ks + 1) & 1], ks + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        wt_mma_block(S, w[ks & 3][0], x[ks & 1]);
-        if (ks + 4 < KS1) w_load<1>(w[ks & 3], wp1, ks + 4, lo8);
+        if constexpr (HALF) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks & 3][0].h[0], x[ks & 1].h[ti], S.t[0][ti], 0, 0, 0);
+                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks & 3][0].l[0], x[ks & 1].h[ti], S.t[0][ti], 0, 0, 0);
+                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks & 3][0].h[0], x[ks & 1].l[ti], S.t[0][ti], 0, 0, 0);
+            }
+        } else {
+            wt_mma_block(S, w[ks & 3][0], x[ks & 1]);
+        }
+        if (ks + 4 < KS1) w_ring_load(ks & 3, ks + 4);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int fi = 0; fi < 2; ++fi) {
-        const int feat = nt * 32 + fi * 16 + 4 * g;
+    for (int fi = 0; fi < (HALF ? 1 : 2); ++fi) {
+        const int feat = nt * 32 + (HALF ? hf : fi) * 16 + 4 * g;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int64_t tok = m0 + ti * 16 + c;
