@@ -813,6 +813,13 @@ static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int 
         if constexpr (EPI == 0 || EPI == 2) {  // 16-feature tiles per wave, twice the workgroups (wt_linear_half_kernel)
             if (N % 64 == 0 && K % 128 == 0) {
                 const int nbn = N / 64;
+                if (K % 256 == 0 && K >= 1024)  // FFN-down: weights eight k-steps ahead
+                    hipLaunchKernelGGL((wt_linear_half_kernel<EPI, 8>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K, Wp,
+                                       N, bias, out, (const _Float16*)oh, (const _Float16*)ol, nbn);
+                else if (K % 384 == 0)  // K = 384: six of the twelve k-steps ahead
+                    hipLaunchKernelGGL((wt_linear_half_kernel<EPI, 6>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K, Wp,
+                                       N, bias, out, (const _Float16*)oh, (const _Float16*)ol, nbn);
+                else
                 hipLaunchKernelGGL((wt_linear_half_kernel<EPI>), dim3(((T + 31) / 32) * nbn), dim3(256), 0, st, Xh, Xl, T, K, Wp, N,
                                    bias, out, (const _Float16*)oh, (const _Float16*)ol, nbn);
                 return;

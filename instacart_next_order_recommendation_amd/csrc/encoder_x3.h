@@ -539,7 +539,7 @@ __device__ __forceinline__ void ffn_x_frag(XFrag& x, const char* Xs, const int (
 // MFMAs) and a workgroup 32 tokens x 64 features: twice the workgroups, half the bytes and half the MFMA chain per CU
 // (measured, same box: FFN-down -12 us per request, attention-out another -10 us; profiles/r04_single_request_anatomy.txt).
 // Per output the chain is wt_kloop's (k-steps ascending, (w_hi,x_hi), (w_lo,x_hi), (w_hi,x_lo)): identical bits.
-template <int EPI>  // 0: out = acc * 2^-14 + bias; 2: residual planes rh / rl + bias added after the loop, out = that * 2^-14
+template <int EPI, int D = 4>  // 0: out = acc * 2^-14 + bias; 2: residual planes rh / rl + bias added after the loop, out = that * 2^-14
 __global__ __launch_bounds__(256, 2) void wt_linear_half_kernel(const _Float16* __restrict__ Xh,
                                                                     const _Float16* __restrict__ Xl, int T, int K,
                                                                     const _Float16* __restrict__ Wp, int N,
@@ -555,7 +555,8 @@ __global__ __launch_bounds__(256, 2) void wt_linear_half_kernel(const _Float16* 
     const unsigned lo8 = lane * 8;
     const int KS = K / 32, nslab = K / 64;
     const _Float16* const wp = Wp + wt_frag_off(nt, 0, KS) + (size_t)fi * (2 * WT_FRAG);
-    half8 wh[4], wl[4];
+    static_assert(D == 4 || D == 6 || D == 8, "ring depth: 4, 6 (K a multiple of 384) or 8 (K a multiple of 256) k-steps");
+    half8 wh[D], wl[D];
     auto w_load1 = [&](int slot, int ks) {
         const _Float16* p = wp + (size_t)ks * (4 * WT_FRAG);
         wh[slot] = *reinterpret_cast<const half8*>(p + lo8);
@@ -565,12 +566,12 @@ __global__ __launch_bounds__(256, 2) void wt_linear_half_kernel(const _Float16* 
     u32x4 xa[2], xb[2];
     x_load<1>(xa, Xh, Xl, m0, T, K, 0);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) w_load1(d, d);
+    for (int d = 0; d < D; ++d) w_load1(d, d);
     if (nslab > 1) x_load<1>(xb, Xh, Xl, m0, T, K, 1);
     x_store<1>(xa, smem);
     if (nslab > 2) x_load<1>(xa, Xh, Xl, m0, T, K, 2);
     __syncthreads();
-    auto slab = [&](int s, auto parity, u32x4 (&xnext)[2]) {  // as wt_kloop<1, 1, 4>: ring slot of k-step 2 s + j is 2 PAR + j
+    auto slab = [&](int s, auto parity, u32x4 (&xnext)[2]) {  // as wt_kloop<1, 1, D>: ring slot of k-step 2 s + j is 2 PAR + j
         constexpr int PAR = decltype(parity)::value;
         const char* st = smem + (s & 1) * XRing<1>::STAGE_BYTES;
         XFrag x[2];
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_half_kernel(const _Float16* 
                 acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[2 * PAR + j], x[j].l[ti], acc[ti], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            int nk = 2 * s + j + 4;
+            int nk = 2 * s + j + D;
             nk = nk < KS ? nk : KS - 1;
             w_load1(2 * PAR + j, nk);
             __builtin_amdgcn_sched_barrier(0);
@@ -599,9 +600,26 @@ __global__ __launch_bounds__(256, 2) void wt_linear_half_kernel(const _Float16* 
         }
         __syncthreads();
     };
-    for (int s = 0; s < nslab; s += 2) {
-        slab(s, std::integral_constant<int, 0>{}, xb);
-        slab(s + 1, std::integral_constant<int, 1>{}, xa);
+    // the ring slot of k-step 2 s + j is 2 (s % (D / 2)) + j, the register buffer of the next slab alternates with s & 1: a trip of
+    // the unrolled loop covers lcm(D / 2, 2) slabs (the host checks that nslab is a multiple of it)
+    if constexpr (D == 6) {
+        for (int s = 0; s < nslab; s += 6) {
+            slab(s, std::integral_constant<int, 0>{}, xb);
+            slab(s + 1, std::integral_constant<int, 1>{}, xa);
+            slab(s + 2, std::integral_constant<int, 2>{}, xb);
+            slab(s + 3, std::integral_constant<int, 0>{}, xa);
+            slab(s + 4, std::integral_constant<int, 1>{}, xb);
+            slab(s + 5, std::integral_constant<int, 2>{}, xa);
+        }
+    } else {
+        for (int s = 0; s < nslab; s += D / 2) {
+            slab(s, std::integral_constant<int, 0>{}, xb);
+            slab(s + 1, std::integral_constant<int, 1>{}, xa);
+            if constexpr (D == 8) {
+                slab(s + 2, std::integral_constant<int, 2>{}, xb);
+                slab(s + 3, std::integral_constant<int, 3>{}, xa);
+            }
+        }
     }
     const int feat = nt * 32 + fi * 16 + 4 * g;
     const f32x4 b = *reinterpret_cast<const f32x4*>(bias + feat);
@@ -654,7 +672,8 @@ __global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __r
     const int ft = nb * 4 + wq;                       // HALF: 16-feature tile index
     const int nt = HALF ? ft >> 1 : ft, hf = ft & 1;  // the 32-feature block; HALF: which half of it
     const unsigned lo8 = lane * 8;
-    WFrag w[4][1];  // HALF: only [hf] of h / l is loaded and used
+    constexpr int RD = 8;  // weight ring depth in k-steps: eight of the twelve are requested in front of the LayerNorm
+    WFrag w[RD][1];  // HALF: only [hf] of h / l is loaded and used
     const _Float16* const wp1[1] = {Wp + wt_frag_off(nt, 0, KS1)};
     auto w_ring_load = [&](int slot, int ks) {
         if constexpr (HALF) {
@@ -666,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __r
         }
     };
 #pragma unroll
-    for (int d = 0; d < 4; ++d) w_ring_load(d, d);
+    for (int d = 0; d < RD; ++d) w_ring_load(d, d);
     f32x4 bv[2];
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) bv[fi] = *reinterpret_cast<const f32x4*>(bias + nt * 32 + (HALF ? hf : fi) * 16 + 4 * g);
@@ -759,14 +778,14 @@ __global__ __launch_bounds__(256, 2) void wt_linear_lnin_kernel(const float* __r
         if constexpr (HALF) {
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
-                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks & 3][0].h[0], x[ks & 1].h[ti], S.t[0][ti], 0, 0, 0);
-                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks & 3][0].l[0], x[ks & 1].h[ti], S.t[0][ti], 0, 0, 0);
-                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks & 3][0].h[0], x[ks & 1].l[ti], S.t[0][ti], 0, 0, 0);
+                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks % RD][0].h[0], x[ks & 1].h[ti], S.t[0][ti], 0, 0, 0);
+                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks % RD][0].l[0], x[ks & 1].h[ti], S.t[0][ti], 0, 0, 0);
+                S.t[0][ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks % RD][0].h[0], x[ks & 1].l[ti], S.t[0][ti], 0, 0, 0);
             }
         } else {
-            wt_mma_block(S, w[ks & 3][0], x[ks & 1]);
+            wt_mma_block(S, w[ks % RD][0], x[ks & 1]);
         }
-        if (ks + 4 < KS1) w_ring_load(ks & 3, ks + 4);
+        if (ks + RD < KS1) w_ring_load(ks % RD, ks + RD);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
