@@ -737,6 +737,11 @@ struct Encoder {
     //                        FFN-up, FFN-down + LayerNorm as separate launches in natural sequence order (same bits)
     //   ICREC_SIDE_STREAM=0  every kernel on the caller's stream (no side stream for the batch remainder / short buckets)
     bool fuse = true, side_stream = true;
+    //   ICREC_SMALL_M=n      token count up to which a call takes the latency-form kernels (32-token x 64-feature
+    //                        workgroups, every GEMM a launch of its own) instead of the layer kernel (one 64-token workgroup
+    //                        per CU).  Round 4: 3,584 - measured crossover ~4,000 tokens (tools/small_m_sweep.py: 897 tokens
+    //                        0.39 ms against 0.79, 2,900 tokens 0.74 against 0.86, 4,485 tokens 0.86 against 0.82); rounds 1-3: 512
+    int small_m = 3584;
     // Side stream + events of one caller stream: the short remainder of a large batch (batch_split) and the shorter
     // attention buckets run beside the batch kernels of the same layer instead of behind them.  One set per caller
     // stream (created on first use, kept for the encoder's life), so that concurrent icrec_encode calls on different
@@ -808,8 +813,8 @@ static void launch_linear(const float* A, int M, int K, const float* W, int N, c
 // wave).  Per-output arithmetic is the same chain in both, so a request encodes to the same bits either way.
 template <int EPI>
 static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int K, const _Float16* Wp, int N,
-                             const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st) {
-    if (T <= X3_SMALL_M) {
+                             const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st, int small_m) {
+    if (T <= small_m) {
         if constexpr (EPI == 0 || EPI == 2) {  // 16-feature tiles per wave, twice the workgroups (wt_linear_half_kernel)
             if (N % 64 == 0 && K % 128 == 0) {
                 const int nbn = N / 64;
@@ -898,6 +903,7 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
         const char* fuse_env = getenv("ICREC_FUSE");
         const char* side_env = getenv("ICREC_SIDE_STREAM");
         e->fuse = !(fuse_env && fuse_env[0] == '0');
+        if (const char* sm = getenv("ICREC_SMALL_M")) { const int v = atoi(sm); if (v >= 0) e->small_m = v; }
         e->side_stream = !(side_env && side_env[0] == '0');
     }
     const size_t H = cfg->hidden, I = cfg->intermediate;
@@ -985,7 +991,7 @@ static void batch_split(const Encoder* e, int T, int* t_main, int* t_tail) {
     const int round_tokens = 64 * e->n_cu;
     *t_main = T;
     *t_tail = 0;
-    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= X3_SMALL_M) {
+    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= X3_SMALL_M) {  // (the remainder rule keeps its own bound)
         *t_tail = T % round_tokens;
         *t_main = T - *t_tail;
     }
@@ -1030,6 +1036,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
     int T_main, T_tail;
     batch_split(e, T, &T_main, &T_tail);
     const bool fuse = e->fuse, side_stream = e->side_stream;
+    const int small_m = e->small_m;
     const bool qkv_res = fuse && H == 384;
     const bool lnin = fuse && H == 384 && I % 64 == 0;  // small ranges: LayerNorms folded into the consuming GEMMs
     const bool split_att = x3 && side_stream && n_seqs >= 64 && max_seqlen > 128;  // batches with a long bucket
@@ -1067,14 +1074,14 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             // CU, a short remainder [T_main, T) through the small-batch kernels (same arithmetic, same bits) instead
             // of costing every batch kernel an extra, almost empty round.
             auto qkv_stage = [&](int r0, int Tn, hipStream_t st) -> int {
-                if (Tn > X3_SMALL_M && qkv_res) {  // activation-resident form: one 64-token workgroup per CU
+                if (Tn > small_m && qkv_res) {  // activation-resident form: one 64-token workgroup per CU
                     auto kern = qkv_resident_kernel;
                     if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), QKVR_LDS)) return rc_;
                     hipLaunchKernelGGL(kern, dim3((Tn + 63) / 64), dim3(512), QKVR_LDS, st, xh + (size_t)r0 * H,
                                        xl + (size_t)r0 * H, Tn, L.Wqkv_p, L.bqkv, qkv + (size_t)r0 * 3 * H, 3 * H);
                     return ICREC_OK;
                 }
-                if (lnin && l > 0 && Tn <= X3_SMALL_M) {
+                if (lnin && l > 0 && Tn <= small_m) {
                     // small ranges: the previous layer's FFN LayerNorm is this kernel's prologue (t1 rows -> planes in LDS
                     // and, from the workgroups of feature block 0, to xh / xl): one graph node fewer per layer
                     const LayerW& Lp = e->layers[l - 1];
@@ -1086,14 +1093,14 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     return ICREC_OK;
                 }
                 launch_wt_linear<0>(xh + (size_t)r0 * H, xl + (size_t)r0 * H, Tn, H, L.Wqkv_p, 3 * H, L.bqkv,
-                                    qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st);
+                                    qkv + (size_t)r0 * 3 * H, nullptr, nullptr, st, small_m);
                 return ICREC_OK;
             };
             auto post_stage = [&](int r0, int Tn, hipStream_t st) -> int {
                 float* const t1r = t1 + (size_t)r0 * H;
                 _Float16 *const xhr = xh + (size_t)r0 * H, *const xlr = xl + (size_t)r0 * H;
                 const _Float16 *const chr = ch + (size_t)r0 * H, *const clr = cl + (size_t)r0 * H;
-                if (Tn > X3_SMALL_M && fuse) {
+                if (Tn > small_m && fuse) {
                     // attention-out + residual + LN and the whole FFN block + residual + LN: ONE kernel per half layer
                     // (x1 stays on chip between the two LayerNorm sites)
                     ScopedTimer tm(T_FFN_UP, st);
@@ -1109,8 +1116,8 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                                        qkv + (size_t)r0 * 3 * H, 3 * H);
                 } else {
                     _Float16 *const hhr = hh + (size_t)r0 * I, *const hlr = hl + (size_t)r0 * I;
-                    launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st);  // residual: x planes
-                    if (lnin && Tn <= X3_SMALL_M) {  // LayerNorm + FFN-up in one node (wt_linear_lnin_kernel)
+                    launch_wt_linear<2>(chr, clr, Tn, H, L.Wo_p, H, L.bo, t1r, xhr, xlr, st, small_m);  // residual: x planes
+                    if (lnin && Tn <= small_m) {  // LayerNorm + FFN-up in one node (wt_linear_lnin_kernel)
                         const int nbn = I / 64;
                         hipLaunchKernelGGL((wt_linear_lnin_kernel<1, true>), dim3(((Tn + 31) / 32) * nbn), dim3(256), 0, st,
                                            (const float*)t1r, Tn, L.g1, L.b1n, c.ln_eps, xhr, xlr, L.W1_p, I, L.b1,
@@ -1119,13 +1126,13 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
                     hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 15) / 16), dim3(256), 0, st, t1r, Tn, L.g1, L.b1n,
                                        c.ln_eps, xhr, xlr);
                     {
-                        ScopedTimer tm(Tn > X3_SMALL_M ? T_FFN_UP : T_NSLOTS - 1, st);
-                        launch_wt_linear<1>(xhr, xlr, Tn, H, L.W1_p, I, L.b1, nullptr, hhr, hlr, st);
+                        ScopedTimer tm(Tn > small_m ? T_FFN_UP : T_NSLOTS - 1, st);
+                        launch_wt_linear<1>(xhr, xlr, Tn, H, L.W1_p, I, L.b1, nullptr, hhr, hlr, st, small_m);
                     }
                     }
-                    launch_wt_linear<2>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, xhr, xlr, st);
+                    launch_wt_linear<2>(hhr, hlr, Tn, I, L.W2_p, H, L.b2, t1r, xhr, xlr, st, small_m);
                     // the FFN LayerNorm: the prologue of the next layer's QKV projection (qkv_stage) - but for the last layer
-                    if (!(lnin && Tn <= X3_SMALL_M && l + 1 < c.layers))
+                    if (!(lnin && Tn <= small_m && l + 1 < c.layers))
                     hipLaunchKernelGGL(ln_wt_kernel, dim3((Tn + 15) / 16), dim3(256), 0, st, t1r, Tn, L.g2, L.b2n,
                                        c.ln_eps, xhr, xlr);
                 }
@@ -1148,7 +1155,7 @@ int icrec_encode(icrec_encoder* h, const int32_t* ids_dev, const int32_t* cu_dev
             }
             // batches: layer 0 projects Q / K / V in a launch of its own; every later layer's projection is the epilogue of
             // the previous layer's fused kernel
-            const bool qkv_in_fused = fuse && T_main > X3_SMALL_M && H == 384;
+            const bool qkv_in_fused = fuse && T_main > small_m && H == 384;
             if (l == 0 || !qkv_in_fused)
                 if (int rc_ = qkv_stage(0, T_main, st)) return rc_;
             if (T_tail && use_side) ICREC_HIP(hipStreamWaitEvent(st, sd->ev_qkv_tail, 0));

@@ -88,18 +88,30 @@ def test_attention_bucket_boundaries_alone_equal_in_batch(encoder):
         np.testing.assert_array_equal(one[0], full[s], err_msg=f"length {n}")
 
 
-def test_small_and_batch_gemm_paths_agree_bitwise(encoder):
-    """<= 512 tokens take the small-tile (latency) GEMM kernels, larger batches the 128x128 ones: a request
-    must encode to the same bits through either (same per-output MFMA chains)."""
+def test_small_and_batch_gemm_paths_agree_bitwise(encoder, minilm_weights, monkeypatch):
+    """Calls of up to 3,584 tokens take the latency-form kernels (32-token x 64-feature workgroups, a launch per GEMM),
+    larger batches the layer kernel (one 64-token workgroup per CU): a request must encode to the same bits through
+    either (same per-output MFMA chains, same LayerNorm tree) - alone, inside a 6,000-token batch, and inside a
+    2,400-token batch whichever of the two forms that batch is given (ICREC_SMALL_M at encoder creation)."""
     from instacart_next_order_recommendation_amd import synthetic as syn
+    from instacart_next_order_recommendation_amd.encoder import DeviceEncoder
 
-    ids, cu = syn.synthetic_token_batch(24, seed=33, mean_len=100, std_len=40, lo=5, hi=256)
-    assert cu[-1] > 1024
+    ids, cu = syn.synthetic_token_batch(60, seed=33, mean_len=100, std_len=40, lo=5, hi=256)
+    assert cu[-1] > 3584 + 512
     full = _encode(encoder, ids, cu)
-    for s in [0, 7, 23]:
+    for s in [0, 7, 23, 59]:
         n = int(cu[s + 1] - cu[s])
         one = _encode(encoder, ids[cu[s]:cu[s + 1]].copy(), np.array([0, n], np.int32))
         np.testing.assert_array_equal(one[0], full[s])
+    mid_ids, mid_cu = ids[:cu[24]].copy(), cu[:25].copy()
+    assert 1024 < mid_cu[-1] <= 3584
+    mid = _encode(encoder, mid_ids, mid_cu)                       # latency form
+    np.testing.assert_array_equal(mid, full[:24])
+    monkeypatch.setenv("ICREC_SMALL_M", "512")
+    batch_form = DeviceEncoder(minilm_weights, gemm_mode=encoder.gemm_mode)  # the same 2,400 tokens through the layer kernel
+    monkeypatch.delenv("ICREC_SMALL_M")
+    np.testing.assert_array_equal(_encode(batch_form, mid_ids, mid_cu), mid)
+    batch_form.close()
 
 
 def test_n_normalize_variants(minilm_weights):
@@ -188,9 +200,10 @@ def test_two_stream_split_is_bitwise_identical(encoder):
         np.testing.assert_array_equal(one, two)
 
 
-@pytest.mark.parametrize("n_seqs", [19, 400])
+@pytest.mark.parametrize("n_seqs", [19, 60, 400])
 def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, n_seqs):
-    """Batches above 512 tokens run the activation-resident QKV kernel, attention with the longest-first dispatch
+    """Batches above 3,584 tokens (60 and 400 sequences here; the 19 take the latency-form kernels, whose LayerNorms are
+    folded into the GEMMs - also compared) run the activation-resident QKV kernel, attention with the longest-first dispatch
     order, attention-out + residual + LN and the whole FFN block (up, GELU, down, residual, LN) as fused kernels.
     An encoder created under ICREC_FUSE=0 (the switch is read once, at icrec_encoder_create) runs the UNFUSED
     reference chain: slab-ring QKV, attention in batch order, separate GEMM / LayerNorm launches.  Same per-output
@@ -205,7 +218,7 @@ def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, 
     ref = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
     monkeypatch.delenv("ICREC_FUSE")
     ids, cu = syn.synthetic_token_batch(n_seqs, seed=5, mean_len=90, std_len=60, lo=3, hi=256)
-    assert int(cu[-1]) > (512 if n_seqs == 19 else 2 * 64 * 256)
+    assert int(cu[-1]) > {19: 512, 60: 3584, 400: 2 * 64 * 256}[n_seqs]
     mx = int(np.diff(cu).max())
     args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), mx)
     fused = enc.encode_packed(*args).cpu().numpy()
@@ -217,9 +230,9 @@ def test_fused_layer_kernels_equal_unfused_bitwise(minilm_weights, monkeypatch, 
     ref.close()
 
 
-@pytest.mark.parametrize("lens", [[99], [1], [33, 1, 32, 31, 64, 200], [256, 255]])
+@pytest.mark.parametrize("lens", [[99], [1], [33, 1, 32, 31, 64, 200], [256, 255], [150] * 22 + [7, 201]])
 def test_small_batches_with_layernorms_folded_into_the_gemms_bitwise(minilm_weights, monkeypatch, lens):
-    """Up to 512 tokens the two LayerNorms of a layer are the prologues of the GEMMs that consume them
+    """Up to 3,584 tokens the two LayerNorms of a layer are the prologues of the GEMMs that consume them
     (wt_linear_lnin_kernel: FFN-up, the next layer's QKV projection; the last layer's FFN LayerNorm stays a kernel) -
     11 graph nodes fewer per request.  ICREC_FUSE=0 keeps the separate ln_wt_kernel launches: same arithmetic thread for
     thread => identical bits; rows of a 32-token block past the end of the batch never reach a real row."""
@@ -234,7 +247,7 @@ def test_small_batches_with_layernorms_folded_into_the_gemms_bitwise(minilm_weig
     rng = np.random.default_rng(len(lens))
     ids = rng.integers(1000, 30000, size=int(np.sum(lens))).astype(np.int32)
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    assert int(cu[-1]) <= 512
+    assert int(cu[-1]) <= 3584
     args = (torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda(), int(max(lens)))
     got = enc.encode_packed(*args).cpu().numpy()
     want = ref.encode_packed(*args).cpu().numpy()
