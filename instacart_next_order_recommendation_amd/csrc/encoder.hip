@@ -797,7 +797,7 @@ static EncWs enc_ws(const icrec_bert_cfg& c, int64_t T) {
 }
 
 typedef TileCfg<2, 2, 2, 2> GemmBig;  // 128 x 128 output tile, 4 waves
-constexpr int X3_SMALL_M = 512;  // <= this many tokens: the latency form (32-token x 128-feature blocks, many workgroups)
+constexpr int X3_SMALL_M = 512;  // a batch's remainder of up to this many tokens goes through the latency-form kernels (batch_split)
 
 template <bool GELU>
 static void launch_linear(const float* A, int M, int K, const float* W, int N, const float* bias, float* out,
@@ -807,10 +807,12 @@ static void launch_linear(const float* A, int M, int K, const float* W, int N, c
                        bias, out, nt);
 }
 
-// f16x3 linear layer through the weights-direct engine.  Single requests / micro-batches are latency-bound (a
-// handful of workgroups, each walking its K loop): they use 32-token x 128-feature blocks — one 32x32 tile per
-// wave, as many workgroups as the shape allows; batches use 64-token x 384-feature blocks (3 x 2 tiles per
-// wave).  Per-output arithmetic is the same chain in both, so a request encodes to the same bits either way.
+// f16x3 linear layer through the weights-direct engine.  Single requests / micro-batches (up to small_m tokens) are
+// latency-bound - a handful of workgroups, each walking its K loop at the rate ONE CU's vector L1 pulls fragments from
+// L2: they use 32-token x 64-feature workgroups, one 16-feature tile per wave (wt_linear_half_kernel; EPI 1 keeps the
+// 32 x 128 form: its small-batch consumer is wt_linear_lnin_kernel), as many workgroups as the shape allows; batches use
+// 64-token x 384-feature blocks (3 x 2 tiles per wave).  Per-output arithmetic is the same chain in all of them, so a
+// request encodes to the same bits either way.
 template <int EPI>
 static void launch_wt_linear(const _Float16* Xh, const _Float16* Xl, int T, int K, const _Float16* Wp, int N,
                              const float* bias, float* out, _Float16* oh, _Float16* ol, hipStream_t st, int small_m) {

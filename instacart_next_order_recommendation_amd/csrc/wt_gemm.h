@@ -59,8 +59,8 @@ __device__ __forceinline__ void split_scaled(float x, float scale, _Float16& hi,
 //   lo = f16(s - hi), the subtraction by v_fma_mix_f32 (hi read as the f16 it is, times -1, plus s: exact in fp32, no
 //   conversion back), again v_cvt_pkrtz.
 // (Rounds 1-3 built hi by clearing the low 13 mantissa bits of s: the same value wherever s is in f16's normal range,
-// six instructions per pair.  The attention kernels are bound by vector issue - 4.5 waves per SIMD at ~20 % VALU each -
-// and a third of their per-score work was this split.)  hi + lo carries s to 2^-21 relative (lo is rounded toward zero:
+// six instructions per pair.  In their compute phase the attention kernels are co-limited by vector issue and the matrix
+// pipe, and a third of their per-score vector work was this split: 7-8-tile bucket -13 %.)  hi + lo carries s to 2^-21 relative (lo is rounded toward zero:
 // one ulp of an 11-bit residual); below the f16 normal range (|x| < 3.8e-6) the absolute error is < 2^-24 / 16; beyond
 // it (|x| > 4094) hi saturates at +-65504 and lo takes what it can of the rest.  Every producer of activation planes
 // uses this one function, so a tensor's planes are the same bits whichever kernel wrote them.
@@ -219,8 +219,8 @@ __device__ unsigned long long g_stamps[1 << 22];
 // ---------------------------------------------------------------- whole-K loop of one output tile
 // acc[i][tt] = sum_k W[(nt0 + i) block][k] . X[m0 + tt block][k], K in slabs of 64 (2 k-steps of 32); weight fragments
 // D k-steps ahead in registers (D = 1, 2 or 4: the latency form of single requests keeps four - its few workgroups
-// find a layer's fragments in the Infinity Cache at best, half a microsecond away; eight over the 48 k-steps of FFN-down
-// measured 5 us SLOWER per request, round 4), the next activation slab one slab
+// find a layer's fragments in the Infinity Cache at best, half a microsecond away; eight measured SLOWER at 4 KB per wave and
+// k-step, and faster once a wave's k-step is 2 KB: wt_linear_half_kernel, encoder_x3.h), the next activation slab one slab
 // ahead in registers, two LDS stages, one barrier per slab.  `smem`: XRing<TTW>::BYTES.  The fragments of the next (k-step, token block) unit are read from LDS
 // under the current unit's MFMAs.
 template <int NTW, int TTW, int D>
