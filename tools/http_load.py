@@ -86,10 +86,27 @@ def main():
     for p in clients:
         p.start()
     time.sleep(1.5)  # let every generator import and connect-ready
+
+    def cpu_s(ps):  # user + system CPU seconds of each process (and its threads)
+        import psutil
+        out = []
+        for p_ in ps:
+            try:
+                t = psutil.Process(p_.pid).cpu_times()
+                out.append(t.user + t.system)
+            except Exception:  # noqa: BLE001
+                out.append(float("nan"))
+        return out
+
+    cpu0 = cpu_s(procs), cpu_s(clients)
     t0 = time.perf_counter()
     evt.set()
     res = [q.get() for _ in clients]
     wall = time.perf_counter() - t0
+    cpu1 = cpu_s(procs), cpu_s(clients)
+    busy = lambda a, b: [round((y - x) / wall, 2) for x, y in zip(a, b)]  # noqa: E731
+    cpu_split = {"gpu_worker": busy(cpu0[0][:1], cpu1[0][:1])[0], "front_ends": busy(cpu0[0][1:], cpu1[0][1:]),
+                 "load_generators": busy(cpu0[1], cpu1[1])}
     for p in clients:
         p.join()
     for p in procs:
@@ -107,7 +124,7 @@ def main():
                       "seconds": round(wall, 2), "requests_ok": n_ok, "requests_failed": n_err, "qps": round(n_ok / wall, 1),
                       "p50_ms": round(lat[n // 2] * 1e3, 2), "p95_ms": round(lat[int(n * 0.95)] * 1e3, 2),
                       "p99_ms": round(lat[int(n * 0.99)] * 1e3, 2), "products": args.products, "server_startup_s": round(startup_s, 1),
-                      "cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+                      "cpu_quota": quota, "os_cpu_count": os.cpu_count(), "cpus_busy_per_process": cpu_split,
                       "note": "real TCP sockets on loopback, HTTP/1.1 keep-alive; 1 GPU-owner process + N FastAPI front-ends "
                               "(asyncio HTTP server) + M load-generator processes share the box's CPU quota"}))
 
