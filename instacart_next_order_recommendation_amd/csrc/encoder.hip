@@ -742,6 +742,12 @@ struct Encoder {
     //                        per CU).  Round 4: 3,584 - measured crossover ~4,000 tokens (tools/small_m_sweep.py: 897 tokens
     //                        0.39 ms against 0.79, 2,900 tokens 0.74 against 0.86, 4,485 tokens 0.86 against 0.82); rounds 1-3: 512
     int small_m = 3584;
+    //   ICREC_TAIL_M=n       a batch's remainder (tokens beyond whole rounds of one 64-token workgroup per CU) of up to n tokens
+    //                        goes through the latency-form kernels on the side stream instead of a partial round (which
+    //                        costs every layer kernel ~0.1 ms: +0.57 ms per step).  Round 4: 2,560 - measured on 1,030- /
+    //                        1,040- / 1,050-context batches (remainders 650 / 1,839 / 3,117 tokens): 9.83 -> 9.35 ms, 9.86 -> 9.60,
+    //                        9.89 -> 9.91 (tools/tail_sweep.sh, profiles/r04_small_m_sweep.txt); rounds 2-3: 512
+    int tail_m = 2560;
     // Side stream + events of one caller stream: the short remainder of a large batch (batch_split) and the shorter
     // attention buckets run beside the batch kernels of the same layer instead of behind them.  One set per caller
     // stream (created on first use, kept for the encoder's life), so that concurrent icrec_encode calls on different
@@ -906,6 +912,7 @@ int icrec_encoder_create(const float* weights_host, size_t n_floats, const icrec
         const char* side_env = getenv("ICREC_SIDE_STREAM");
         e->fuse = !(fuse_env && fuse_env[0] == '0');
         if (const char* sm = getenv("ICREC_SMALL_M")) { const int v = atoi(sm); if (v >= 0) e->small_m = v; }
+        if (const char* tm = getenv("ICREC_TAIL_M")) { const int v = atoi(tm); if (v >= 0) e->tail_m = v; }
         e->side_stream = !(side_env && side_env[0] == '0');
     }
     const size_t H = cfg->hidden, I = cfg->intermediate;
@@ -993,7 +1000,7 @@ static void batch_split(const Encoder* e, int T, int* t_main, int* t_tail) {
     const int round_tokens = 64 * e->n_cu;
     *t_main = T;
     *t_tail = 0;
-    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= X3_SMALL_M) {  // (the remainder rule keeps its own bound)
+    if (T > round_tokens && T % round_tokens != 0 && T % round_tokens <= e->tail_m) {
         *t_tail = T % round_tokens;
         *t_main = T - *t_tail;
     }

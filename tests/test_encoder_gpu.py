@@ -293,6 +293,11 @@ def test_side_stream_changes_nothing(minilm_weights, monkeypatch):
     enc_one_stream.close()
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(a, c)
+    monkeypatch.setenv("ICREC_TAIL_M", "0")        # no remainder rule: the same tokens as a partial round of the batch kernels
+    enc_no_tail = DeviceEncoder(minilm_weights, gemm_mode="f16x3")
+    monkeypatch.delenv("ICREC_TAIL_M")
+    np.testing.assert_array_equal(enc_no_tail.encode_packed(*args).cpu().numpy(), a)
+    enc_no_tail.close()
     # the remainder's sequences encode to the same bits on their own (small-batch kernels on the caller's stream)
     s0 = int(np.searchsorted(cu, main_t, side="right")) - 1
     sub_cu = (cu[s0:] - cu[s0]).astype(np.int32)
