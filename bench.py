@@ -318,6 +318,8 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    verified_excl = [None, None]  # [every rank's exclusion exchange equals the unsharded search, error text of this rank]
+
     def measure(search, batch=None, steps=None, warmup=None, verify=True):
         """W warm-up steps, then exactly K timed steps between two barriers; N > 1: max over ranks and the check of the
         exchange.  `batch` = (ids, cu_seqlens, max_len, out) on the device (default: the step's own batch).
@@ -366,21 +368,51 @@ def main() -> None:
             full = DeviceIndex(torch.from_numpy(catalog).to(dev), dev, storage="f32")
             ref_idx, ref_sc = full.search(q_all[sample], TOP_K)
             same = bool(torch.equal(ref_idx, idx[sample]) and torch.equal(ref_sc, sc[sample])) and idx.shape[0] == n_all
-            mine = idx[rank * n_loc:(rank + 1) * n_loc, :3].cpu().tolist()  # this rank's own queries, gathered order
-            excl_local = [row if (i % 5) else [] for i, row in enumerate(mine)]  # every fifth list empty
-            xi, xs = search.search(b_emb, TOP_K, exclude_local=excl_local, excl_cap=n_loc * 4)
-            all_top3 = idx[:, :3].cpu().tolist()
-            excl_all = [all_top3[g] if ((g % n_loc) % 5) else [] for g in sample.cpu().tolist()]
-            rxi, rxs = full.search(q_all[sample], TOP_K, excl_all)
-            same_excl = bool(torch.equal(rxi, xi[sample]) and torch.equal(rxs, xs[sample]))
+            # the exclusion exchange: its native path (icrec_search_sharded_excl over two more ncclAllGathers) has never run
+            # on more than one GPU before a real multi-GPU launch of this file - an exception there must cost the line its
+            # `exclusion_exchange_verified`, not the whole scaling record
+            same_excl, excl_err = False, None
+            try:
+                mine = idx[rank * n_loc:(rank + 1) * n_loc, :3].cpu().tolist()  # this rank's own queries, gathered order
+                excl_local = [row if (i % 5) else [] for i, row in enumerate(mine)]  # every fifth list empty
+                xi, xs = search.search(b_emb, TOP_K, exclude_local=excl_local, excl_cap=n_loc * 4)
+                all_top3 = idx[:, :3].cpu().tolist()
+                excl_all = [all_top3[g] if ((g % n_loc) % 5) else [] for g in sample.cpu().tolist()]
+                rxi, rxs = full.search(q_all[sample], TOP_K, excl_all)
+                same_excl = bool(torch.equal(rxi, xi[sample]) and torch.equal(rxs, xs[sample]))
+            except Exception as exc:  # noqa: BLE001
+                excl_err = f"{type(exc).__name__}: {exc}"
+                print(f"rank {rank}: exclusion exchange check raised {excl_err}", file=sys.stderr)
             flag = torch.tensor([1 if same else 0, 1 if same_excl else 0], device=dev)
             if dist.get_backend() == "gloo":
                 flag = flag.cpu()
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # the same verdict on every rank
-            verified = bool(int(flag[0].item()) == 1 and int(flag[1].item()) == 1)
+            verified = bool(int(flag[0].item()) == 1)
+            verified_excl[0] = bool(int(flag[1].item()) == 1)
+            verified_excl[1] = excl_err
             full.close()
         return elapsed, idx, sc, timers, verified
 
+    if comm is not None:
+        # one probe step before anything is timed: icrec_search_sharded over more than one rank has never run before a real
+        # multi-GPU launch of this file.  If it raises (on every rank alike: an RCCL error is returned to all of them), the
+        # ranks agree through torch.distributed and measure with the exchange through torch.distributed instead of dying.
+        probe_ok = 1
+        try:
+            enc.encode_packed(ids_d, cu_d, max_len, out=emb)
+            search.search(emb, TOP_K)
+            torch.cuda.synchronize(dev)
+        except Exception as exc:  # noqa: BLE001
+            probe_ok = 0
+            comm_note = f"icrec_search_sharded raised on the probe step ({type(exc).__name__}: {exc}); exchange through torch.distributed (RCCL) instead"
+            print(f"rank {rank}: {comm_note}", file=sys.stderr)
+        t_ok = torch.tensor([probe_ok], device=dev)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
+            comm_note = comm_note or "icrec_search_sharded raised on another rank's probe step; exchange through torch.distributed (RCCL) instead"
+            comm.close()
+            comm = None
+            search = ShardedSearch(backend, lo, hi, comm=None)
     elapsed, idx, sc, timers, exchange_verified = measure(search)
     if exchange_verified is False and comm is not None:
         # the library's own exchange (icrec_search_sharded over ncclAllGather) has never run on more than one GPU before
@@ -707,10 +739,12 @@ def main() -> None:
             "http": http, "http_qps": None if not http else http.get("http_qps"),
             "http_p50_ms": None if not http else http.get("http_p50_ms"),
             "exchange_verified": exchange_verified,
+            "exclusion_exchange_verified": verified_excl[0], "exclusion_exchange_error": verified_excl[1],
             "exchange_verified_note": None if exchange_verified is None else
             ("every rank: 64-query sample of the gathered batch searched against a replicated unsharded index, indices and scores "
-             "bit-equal; then again with per-rank exclusion lists (each local query's own top-3 rows, every fifth list empty) "
-             "through the exclusion exchange against the unsharded search with the gathered lists"),
+             "bit-equal (false: the run is re-measured with the exchange through torch.distributed, or fails); "
+             "exclusion_exchange_verified: the same sample again with per-rank exclusion lists (each local query's own top-3 rows, "
+             "every fifth list empty) through the exclusion exchange against the unsharded search with the gathered lists"),
             "exchange": None if world == 1 else ("icrec_search_sharded (RCCL inside libicrec)" if comm is not None else
                                                  (comm_note or "torch.distributed collectives (gloo rehearsal)")),
             "p50_latency_ms_single_request": p50_ms,

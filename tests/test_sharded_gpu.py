@@ -74,7 +74,7 @@ def test_bench_multi_rank_flow_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["rehearsal_not_a_measurement"]
     assert d["config"]["contexts_per_gpu_per_step"] == 64
-    assert d["exchange_verified"] is True
+    assert d["exchange_verified"] is True and d["exclusion_exchange_verified"] is True
     leg = d["configs4_10m_rows"]
     assert leg["queries_per_step"] == 4096 and leg["contexts_encoded_per_gpu"] == 2048 and leg["rows_per_gpu"] == 150000
     assert leg["result_properties_ok"] and leg["qps"] > 0
