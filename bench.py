@@ -193,15 +193,16 @@ def self_launch(args) -> None:
 def http_leg(seconds: float = 3.0) -> dict:
     """/recommend over HTTP (north_star words the target as "/recommend QPS"; reference surface
     src/api/routes/recommend.py:84-199, src/api/schemas.py:15-70): tools/http_load.py as a CHILD process — it starts
-    api/serve.py (1 GPU-owner process + 8 FastAPI front-ends on one port) on the synthetic 49,688-product catalog and 4
-    load-generator processes holding 256 keep-alive connections that POST user contexts (top_k 20) back to back.
-    Everything shares this box's CPU quota (16 CPUs on the GPU box: 9 server processes + 4 generators), so the figure is
-    a host-side number; per-request `recommendation_served` log records are off (METRICS_LOG_LEVEL=WARNING).
+    api/serve.py (3 GPU-owner processes on the one GPU + 10 FastAPI front-ends on one port: a GPU owner is one Python thread
+    and saturates at ~19 k requests per second) on the synthetic 49,688-product catalog and 4 load-generator processes holding
+    256 keep-alive connections that POST user contexts (top_k 20) back to back.  Everything shares this box's CPU quota (16
+    CPUs on the GPU box: 13 server processes + 4 generators), so the figure is a host-side number; per-request
+    `recommendation_served` log records are off (METRICS_LOG_LEVEL=WARNING).
     Runs before this process touches the GPU."""
     import subprocess
 
     env = dict(os.environ, METRICS_LOG_LEVEL="WARNING", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, str(ROOT / "tools" / "http_load.py"), "--frontends", "8", "--client-procs", "4",
+    cmd = [sys.executable, str(ROOT / "tools" / "http_load.py"), "--gpu-workers", "3", "--frontends", "10", "--client-procs", "4",
            "--clients", "256", "--seconds", str(seconds)]
     t0 = time.perf_counter()
     try:
@@ -214,12 +215,14 @@ def http_leg(seconds: float = 3.0) -> dict:
         return {"error": f"{type(exc).__name__}: {exc}"}
     return {"http_qps": d["qps"], "http_p50_ms": d["p50_ms"], "http_p95_ms": d["p95_ms"], "http_p99_ms": d["p99_ms"],
             "failed": d["requests_failed"], "requests_ok": d["requests_ok"], "seconds": d["seconds"],
-            "frontends": d["frontends"], "load_generator_processes": d["client_procs"], "connections": d["connections"],
+            "gpu_workers": d.get("gpu_workers", 1), "frontends": d["frontends"], "load_generator_processes": d["client_procs"],
+            "connections": d["connections"], "cpus_busy_per_process": d.get("cpus_busy_per_process"),
             "cpu_quota": d["cpu_quota"], "server_startup_s": d["server_startup_s"], "top_k": TOP_K,
             "leg_wall_s": round(time.perf_counter() - t0, 1),
-            "note": "POST /recommend over loopback TCP, HTTP/1.1 keep-alive, through api/serve.py: 1 GPU-owner process "
-                    "(tokenise + micro-batch + the same encode/search calls as `value`) + 8 FastAPI front-ends, driven by 4 "
-                    "generator processes on the same CPU quota; 0 failed is part of the claim; metrics log records off"}
+            "note": "POST /recommend over loopback TCP, HTTP/1.1 keep-alive, through api/serve.py --gpu-workers 3: 3 GPU-owner "
+                    "processes on the one GPU (tokenise + micro-batch + the same encode/search calls as `value`) + 10 FastAPI "
+                    "front-ends, driven by 4 generator processes on the same CPU quota; 0 failed is part of the claim; metrics log "
+                    "records off"}
 
 
 def main() -> None:

@@ -11,7 +11,8 @@ src/api/auth.py:39-71 (X-API-Key / Bearer).  Differences, all deliberate:
 Env: MODEL_DIR, CORPUS_PATH, API_KEY, INFERENCE_DEVICE, MAX_CORPUS_UPLOAD_PRODUCTS,
      BATCH_MAX_SIZE (256), BATCH_MAX_WAIT_MS (2).
      ICREC_GPU_WORKER_SOCKET: this process is an HTTP front-end of the multi-process server (serve.py): it loads
-     the corpus JSON only and forwards every request to the GPU-owner process (worker.py).
+     the corpus JSON only and forwards every request to the GPU-owner process(es) (worker.py; a comma-separated list of
+     sockets = several GPU owners on one GPU, requests round-robin).
 """
 from __future__ import annotations
 
@@ -59,14 +60,16 @@ def _install(app: FastAPI, recommender, corpus_path, batcher=None) -> None:
 
 def _install_frontend(app: FastAPI, sock_path: str, corpus_path) -> None:
     """Front-end of the multi-process server: corpus texts only + a socket to the GPU worker."""
-    from .remote import CorpusView, RemoteBatcher
+    from .remote import CorpusView, MultiRemoteBatcher, RemoteBatcher
 
     def on_corpus(new_path: str) -> None:  # the worker re-indexed (another front-end's /admin/corpus): reload texts
         app.state.recommender = CorpusView(new_path)
         app.state.corpus_path = Path(new_path)
         app.state.eval_queries_cache = None
 
-    _install(app, CorpusView(corpus_path), corpus_path, RemoteBatcher(sock_path, on_corpus))
+    socks = [p for p in sock_path.split(",") if p]  # serve.py --gpu-workers N hands every front-end all the sockets
+    batcher = RemoteBatcher(socks[0], on_corpus) if len(socks) == 1 else MultiRemoteBatcher(socks, on_corpus)
+    _install(app, CorpusView(corpus_path), corpus_path, batcher)
 
 
 @asynccontextmanager

@@ -115,3 +115,65 @@ def test_frontend_worker_roundtrip_over_sockets(tmp_path, monkeypatch):
                 pass
 
     asyncio.run(scenario())
+
+
+def test_two_gpu_workers_behind_one_frontend(tmp_path):
+    """serve.py --gpu-workers 2: the front-end's MultiRemoteBatcher spreads requests over both GPU-owner processes, a
+    re-index reaches BOTH of them, and a request survives one of them going away (the other answers; 503 only when all
+    are gone)."""
+    from instacart_next_order_recommendation_amd.api.remote import MultiRemoteBatcher, WorkerUnavailable
+    from instacart_next_order_recommendation_amd.api.worker import GpuWorker
+
+    corpus_path = tmp_path / "eval_corpus.json"
+    corpus_path.write_text(json.dumps({str(i): f"Product: P{i}." for i in range(1, 21)}))
+    new_path = tmp_path / "new_corpus.json"
+    new_path.write_text(json.dumps({f"n{i}": f"Product: N{i}." for i in range(6)}))
+    d = tempfile.mkdtemp(prefix="icrec_t2_")
+    socks = [os.path.join(d, "w0.sock"), os.path.join(d, "w1.sock")]
+
+    class Counting(_StubRecommender):
+        calls = {}
+
+        def recommend_batch_timed(self, queries, top_k, excl):
+            Counting.calls[id(self)] = Counting.calls.get(id(self), 0) + len(queries)
+            return super().recommend_batch_timed(queries, top_k, excl)
+
+    async def scenario():
+        workers = [GpuWorker(None, corpus_path, factory=Counting) for _ in socks]
+        servers = [await asyncio.start_unix_server(w.handle, path=p) for w, p in zip(workers, socks)]
+        seen = []
+        mb = MultiRemoteBatcher(socks, on_corpus=seen.append, call_timeout=5.0)
+        await mb.start()
+        try:
+            assert mb.connected
+            res = await asyncio.gather(*[mb.submit("q" * (i + 1), 3, None) for i in range(40)])
+            assert all([p for p, _ in r[0]] == ["1", "2", "3"] for r in res)
+            per_worker = sorted(Counting.calls.values())
+            assert len(per_worker) == 2 and per_worker == [20, 20]          # round-robin
+            path, n = await mb.reindex(str(new_path))
+            assert n == 6 and all(w.recommender.product_ids[0] == "n0" for w in workers)
+            r, _ = await mb.submit("abc", 2, None)
+            assert [p for p, _ in r] == ["n0", "n1"]
+            # one worker goes away: requests keep being answered by the other one
+            servers[0].close()
+            for w in list(workers[0].writers):
+                w.close()
+            await asyncio.sleep(0.2)
+            for _ in range(6):
+                r, _ = await mb.submit("abc", 1, None)
+                assert [p for p, _ in r] == ["n0"]
+            assert not mb.connected
+            servers[1].close()
+            for w in list(workers[1].writers):
+                w.close()
+            await asyncio.sleep(0.2)
+            with pytest.raises(WorkerUnavailable):
+                await mb.submit("abc", 1, None)
+        finally:
+            await mb.stop()
+            for s in servers:
+                s.close()
+            for w in workers:
+                await w.batcher.stop()
+
+    asyncio.run(scenario())

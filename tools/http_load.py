@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--products", type=int, default=49688)
     ap.add_argument("--port", type=int, default=18080)
+    ap.add_argument("--gpu-workers", type=int, default=1)
     args = ap.parse_args()
 
     from instacart_next_order_recommendation_amd import synthetic as syn
@@ -72,7 +73,7 @@ def main():
     corpus.write_text(json.dumps(syn.synthetic_catalog(args.products)))
     os.environ.update(MODEL_DIR=str(model_dir), CORPUS_PATH=str(corpus))
     t0 = time.time()
-    procs, _ = serve.start(args.frontends, "127.0.0.1", args.port, str(model_dir), str(corpus))
+    procs, _ = serve.start(args.frontends, "127.0.0.1", args.port, str(model_dir), str(corpus), args.gpu_workers)
     startup_s = time.time() - t0
     bodies = [json.dumps({"user_context": c, "top_k": 20}).encode() for c in syn.synthetic_user_contexts(4096, seed=5)]
 
@@ -105,7 +106,8 @@ def main():
     wall = time.perf_counter() - t0
     cpu1 = cpu_s(procs), cpu_s(clients)
     busy = lambda a, b: [round((y - x) / wall, 2) for x, y in zip(a, b)]  # noqa: E731
-    cpu_split = {"gpu_worker": busy(cpu0[0][:1], cpu1[0][:1])[0], "front_ends": busy(cpu0[0][1:], cpu1[0][1:]),
+    ng = args.gpu_workers
+    cpu_split = {"gpu_workers": busy(cpu0[0][:ng], cpu1[0][:ng]), "front_ends": busy(cpu0[0][ng:], cpu1[0][ng:]),
                  "load_generators": busy(cpu0[1], cpu1[1])}
     for p in clients:
         p.join()
@@ -120,7 +122,7 @@ def main():
         quota = None if quota[0] == "max" else float(quota[0]) / float(quota[1])
     except Exception:
         quota = None
-    print(json.dumps({"frontends": args.frontends, "client_procs": args.client_procs, "connections": per * args.client_procs,
+    print(json.dumps({"gpu_workers": args.gpu_workers, "frontends": args.frontends, "client_procs": args.client_procs, "connections": per * args.client_procs,
                       "seconds": round(wall, 2), "requests_ok": n_ok, "requests_failed": n_err, "qps": round(n_ok / wall, 1),
                       "p50_ms": round(lat[n // 2] * 1e3, 2), "p95_ms": round(lat[int(n * 0.95)] * 1e3, 2),
                       "p99_ms": round(lat[int(n * 0.99)] * 1e3, 2), "products": args.products, "server_startup_s": round(startup_s, 1),
