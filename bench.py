@@ -487,6 +487,48 @@ def main() -> None:
         dt2 = (time.perf_counter() - t2) / 10
         two_stream = {"qps": args.batch / dt2, "ms_per_step": dt2 * 1e3}
 
+    # ---- the same step replayed from a hipGraph: what the ~35 dependent dispatches of a step cost on
+    # the host / command-processor side.  Not `value`: a serving batch has a different token count every time, and a graph
+    # bakes it; reported so that the gap is a number.
+    graph_leg = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        try:
+            g_idx = torch.empty((args.batch, TOP_K), dtype=torch.int64, device=dev)
+            g_sc = torch.empty((args.batch, TOP_K), dtype=torch.float32, device=dev)
+            g_side = torch.cuda.Stream(dev)
+
+            def gstep():
+                enc.encode_packed(ids_d, cu_d, max_len, out=emb)
+                backend.index.search_into(emb, TOP_K, None, None, g_idx, g_sc)
+
+            g_side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(g_side):
+                for _ in range(2):
+                    gstep()
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=g_side):
+                    gstep()
+                torch.cuda.synchronize(dev)
+                t_e = time.perf_counter()
+                for _ in range(10):
+                    gstep()
+                torch.cuda.synchronize(dev)
+                t_g = time.perf_counter()
+                for _ in range(10):
+                    graph.replay()
+                torch.cuda.synchronize(dev)
+                t_end = time.perf_counter()
+            same = bool(torch.equal(g_idx, idx)) if g_idx.shape == idx.shape else None
+            graph_leg = {"ms_per_step_replayed": (t_end - t_g) / 10 * 1e3, "ms_per_step_kernel_by_kernel_same_loop": (t_g - t_e) / 10 * 1e3,
+                         "qps_replayed": args.batch * 10 / (t_end - t_g), "result_identical_to_timed_step": same,
+                         "note": "encode + search of the step's batch captured once and replayed 10 times, beside 10 eager steps "
+                                 "in the same loop; a graph bakes the batch's token count, which is why `value` does not use one"}
+            del graph
+        except Exception as exc:  # noqa: BLE001 - a diagnostic leg must not take the line down
+            graph_leg = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.current_stream(dev).wait_stream(g_side)
+
     # ---- the same step in the exact-f32 GEMM mode (every linear layer bit-identical to the oracle's fmaf
     # chains), measured in the same run on the same inputs, plus how far the default mode's embeddings and
     # top-20 lists are from it: the record carries a plain-fp32 number next to the f16x3 one.
@@ -754,6 +796,7 @@ def main() -> None:
             "p50_latency_ms_single_request_without_hipgraph": p50_plain_ms,
             "single_request_tokens": int(cu_h[1]),
             "with_two_stream_encode": two_stream,
+            "with_hipgraph_replay": graph_leg,
             "exact_f32_gemm_mode": f32_leg,
             "from_text_in_host_memory": text_path,
             "from_strings_pipelined": strings_pipelined,
